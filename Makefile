@@ -1,0 +1,30 @@
+# Builds the product library (gfx950 only) and the test oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+PKG := umi_collapse_rs_amd
+CSRC := $(PKG)/csrc
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unused-parameter
+
+LIB := $(PKG)/libumihip.so
+SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_api.cpp
+HDRS := $(CSRC)/umihip_internal.h include/umihip.h
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS)
+
+oracle:
+	$(MAKE) -s -C oracle
+
+asm: $(CSRC)/umihip_kernels.hip $(HDRS)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/umihip_kernels.s -x hip $(CSRC)/umihip_kernels.hip \
+	    -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || (cat build/resource_usage.txt; false)
+
+clean:
+	rm -f $(LIB)
+	rm -rf build
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle asm clean

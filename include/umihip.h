@@ -1,0 +1,139 @@
+/*
+ * umihip.h -- C ABI of the MI355X (gfx950) UMI-collapse hot path.
+ *
+ * This is the drop-in boundary for tkob-vh/umi-collapse-rs.  The reference has
+ * no FFI of its own; the seam is its pair of generic traits
+ *     trait Algorithm  { fn apply(..) }                    src/algo/mod.rs:13-20
+ *     trait DataStruct { new / remove_near / contains }    src/data/mod.rs:11-17
+ * called from the bucket loop src/deduplicate_sam.rs:207-233.  Every entry point
+ * below names the reference interface it replaces.  Plain pointers and sizes
+ * only; nothing here throws or unwinds (the reference builds with panic=abort,
+ * Cargo.toml:19): failures come back as a negative status and a thread-local
+ * message from umi_last_error().
+ *
+ * Key format (all entry points): one uint64 per UMI = BitSet.bits[0] of the
+ * reference (src/utils/bitset.rs:9-14) for umi_len <= 21, i.e. base i occupies
+ * bits 3i..3i+2 with A=000 T=101 C=110 G=011 N=100 (src/utils/read.rs:23-31,
+ * src/utils/mod.rs:38-41); nmask = BitSet.n_bits[0] (bits 3i..3i+2 set where
+ * base i is N; src/utils/mod.rs:45-50), NULL when no UMI holds an N.
+ */
+#ifndef UMIHIP_H
+#define UMIHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMI_OK 0
+#define UMI_ERR_ARG (-1)   /* invalid argument */
+#define UMI_ERR_HIP (-2)   /* HIP runtime failure (message has the hipError) */
+#define UMI_ERR_ORDER (-3) /* entries of a bucket are not in rank order / freq < 1 */
+#define UMI_ERR_NOMEM (-4)
+#define UMI_ERR_NODEV (-5) /* no usable gfx950 device */
+#define UMI_ERR_CHAR (-6)  /* character outside ATCGN (reference: panic, utils/mod.rs:77-79) */
+
+#define UMI_ALGO_DIRECTIONAL 0 /* src/algo/directional.rs */
+#define UMI_ALGO_ADJACENCY 1   /* src/algo/adjacency.rs  */
+
+#define UMI_MAX_UMI_LEN 21 /* one 64-bit word per key (3 bits per base) */
+
+typedef struct umi_ctx umi_ctx;   /* one per process/GPU; not re-entrant (the reference calls
+                                     apply strictly sequentially, deduplicate_sam.rs:207) */
+typedef struct umi_data umi_data; /* device-backed DataStruct instance */
+
+/* Counters of one batched call.  n_pairs is the algorithmic unit of work
+ * W = sum_b n_b(n_b-1)/2; ms_* are HIP-event times on the call's
+ * stream and are filled only when the "profile" option is on. */
+typedef struct umi_stats {
+    uint64_t n_umis;
+    uint64_t n_buckets;
+    uint64_t max_bucket;        /* max_umi_count of deduplicate_sam.rs:218 */
+    uint64_t n_kept;            /* deduped_count of deduplicate_sam.rs:219 */
+    uint64_t n_pairs;           /* W */
+    uint64_t n_pairs_evaluated; /* pairs the filter loop covered (tile padding included) */
+    uint64_t n_candidates;      /* filter hits sent to the exact check */
+    uint64_t n_edges;           /* directed edges fed to the collapse */
+    uint32_t n_rounds;          /* label-propagation rounds */
+    uint32_t n_pair_launches;
+    float ms_total;
+    float ms_prep;
+    float ms_pairs;
+    float ms_collapse;
+    float ms_finalize;
+} umi_stats;
+
+/* ---- context ----------------------------------------------------------- */
+int umi_ctx_create(int device_id, umi_ctx **out);
+void umi_ctx_destroy(umi_ctx *ctx);
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char *umi_last_error(void);
+/* Options: "profile" (0/1: record HIP events, fill ms_*), "edge_capacity"
+ * (initial edge-list capacity, entries), "small_max" (largest bucket handled by
+ * the wave-per-chunk kernel).  Unknown name -> UMI_ERR_ARG. */
+int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
+/* 1 if this library was built with device code for gfx950 (always), for loaders */
+int umi_abi_version(void);
+
+/* ---- staging helper: src/utils/mod.rs:63-83 (to_bitset) ---------------- */
+/* n UMIs of umi_len ASCII bytes each, packed back to back -> keys / nmask
+ * (nmask may be NULL).  Host code, no GPU.  UMI_ERR_CHAR where the reference
+ * panics. */
+int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys,
+                    uint64_t *nmask);
+
+/* ---- batched path: replaces the whole bucket loop
+ *      src/deduplicate_sam.rs:207-233 (apply::<UcSAMRead,Naive> per bucket,
+ *      counters :217-219) = Directional/Adjacency::apply
+ *      (src/algo/directional.rs:57-91, src/algo/adjacency.rs:29-63) over the
+ *      Naive store (src/data/naive.rs:26-44). -------------------------------
+ * keys/nmask/freq: N = bucket_off[n_buckets] entries; bucket b owns
+ * [bucket_off[b], bucket_off[b+1]).  Inside a bucket entries MUST already be in
+ * rank order: freq descending (directional.rs:72), ties in first-appearance
+ * order (canonical determinisation); freq >= 1.
+ * percentage = Cli.percentage (src/cli.rs:25-26), k = Cli.k (src/cli.rs:18-19).
+ * adj_max_freq: third argument of remove_near in adjacency.rs:56 (reference: 0).
+ * kept[i] = 1 iff entry i survives; survivors in ascending index order are the
+ * reference's output order (deduplicate_sam.rs:227-231).  root (may be NULL):
+ * global index of the root that removed entry i (ClusterTracker::add_all,
+ * directional.rs:42-44).  stats may be NULL.
+ * Buffers are caller-owned host memory; the library never frees them. */
+int umi_dedup_batch(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask,
+                    const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets,
+                    int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
+                    uint8_t *kept, uint32_t *root, umi_stats *stats);
+
+/* Same contract with keys/nmask/freq/kept/root already resident in this GPU's
+ * HBM (d_*), work enqueued on hip_stream (a hipStream_t, NULL = default
+ * stream); bucket_off stays a host array.  Returns after the results are
+ * complete on the device (the call synchronises the stream to read its
+ * counters). */
+int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                           const int32_t *d_freq, const uint64_t *bucket_off,
+                           uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
+                           int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
+                           void *hip_stream, umi_stats *stats);
+
+/* ---- per-bucket path: 1:1 with trait DataStruct (src/data/mod.rs:11-17) as
+ *      implemented by Naive (src/data/naive.rs).  UMIs are addressed by their
+ *      index in the arrays handed to umi_data_new. -------------------------- */
+/* DataStruct::new (naive.rs:22-24): takes the {umi -> freq} map of one bucket
+ * (n entries, host memory, copied) and builds the all-pairs neighbour lists
+ * dist <= max_edits on the GPU once. */
+int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                 uint32_t n, int umi_len, int max_edits, umi_data **out);
+/* DataStruct::remove_near (naive.rs:26-40): removes and returns every remaining
+ * entry o with dist(query,o) <= k && (dist == 0 || freq[o] <= max_freq).
+ * k must be <= max_edits.  out_idx has capacity n; ascending index order. */
+int umi_data_remove_near(umi_data *d, uint32_t query, int k, int32_t max_freq, uint32_t *out_idx,
+                         uint32_t *out_n);
+/* DataStruct::contains (naive.rs:42-44): 1 / 0, negative on error. */
+int umi_data_contains(const umi_data *d, uint32_t idx);
+/* Drop of the store. */
+void umi_data_free(umi_data *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from helpers import canonical, random_bucket
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    yield c
+    c.close()
+
+
+def make_batch(rng, n_buckets, L, n_mol_max, err=0.05, n_frac=0.0, mean_copies=3.0):
+    keys, nm, fr, off = [], [], [], [0]
+    for _ in range(n_buckets):
+        n_mol = int(rng.integers(0, n_mol_max + 1))
+        umis, freq = random_bucket(rng, n_mol, L, err=err, n_frac=n_frac,
+                                   mean_copies=mean_copies)
+        umis, freq, _ = canonical(umis, freq)
+        k, m = orc.encode_keys(umis)
+        keys.append(k); nm.append(m); fr.extend(freq)
+        off.append(off[-1] + len(umis))
+    keys = np.concatenate(keys) if keys else np.zeros(0, np.uint64)
+    nm = np.concatenate(nm) if nm else np.zeros(0, np.uint64)
+    return keys, nm, np.array(fr, np.int32), np.array(off, np.uint64)
+
+
+def check_against_oracle(ctx, keys, nm, fr, off, L, k, p=0.5, algo=0, amf=0):
+    kept, root, st = ctx.dedup_batch(keys, nm if nm.any() else None, fr, off, L, k, p, algo, amf)
+    okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
+    assert (kept == okept).all(), "kept mask differs at %s" % np.nonzero(kept != okept)[0][:10]
+    assert (root == oroot).all(), "root differs at %s" % np.nonzero(root != oroot)[0][:10]
+    assert st["n_kept"] == int(okept.sum())
+    assert st["n_umis"] == len(keys)
+    n_b = np.diff(off.astype(np.int64))
+    assert st["n_pairs"] == int((n_b * (n_b - 1) // 2).sum())
+    assert st["max_bucket"] == (int(n_b.max()) if len(n_b) else 0)
+    return st
+
+
+def test_kat_g8_g9_batched(ctx, kat):
+    g = kat["G8_bucket"]
+    umis, freq, order = canonical(g["umis"], g["freq"])
+    assert order == g["rank"]
+    keys, nm = orc.encode_keys(umis)
+    kept, root, _ = ctx.dedup_batch(keys, None, freq, [0, len(umis)], 12, g["k"], g["p"])
+    assert [order[i] for i in np.nonzero(kept)[0]] == g["dir"]
+    kept, _, _ = ctx.dedup_batch(keys, None, freq, [0, len(umis)], 12, g["k"], g["p"], algo=1)
+    assert [order[i] for i in np.nonzero(kept)[0]] == g["adj"]
+    g9 = kat["G9_tie"]
+    keys, nm = orc.encode_keys(g9["umis"])
+    for k, exp in ((1, g9["dir_k1"]), (0, g9["dir_k0"])):
+        kept, _, _ = ctx.dedup_batch(keys, None, g9["freq"], [0, 2], 12, k, g9["p"])
+        assert np.nonzero(kept)[0].tolist() == exp
+
+
+@pytest.mark.parametrize("L,k,p,n_frac", [
+    (12, 1, 0.5, 0.0), (12, 0, 0.5, 0.0), (12, 2, 0.5, 0.0), (12, 3, 0.5, 0.01),
+    (12, 1, 0.3, 0.0), (12, 1, 1.0, 0.0), (6, 1, 0.5, 0.05), (16, 2, 0.5, 0.02),
+    (17, 1, 0.5, 0.0), (20, 2, 0.5, 0.0), (20, 2, 0.75, 0.03), (21, 3, 0.5, 0.01),
+    (1, 1, 0.5, 0.0), (3, 1, 0.5, 0.2),
+])
+def test_random_buckets_directional(ctx, L, k, p, n_frac):
+    rng = np.random.default_rng(100 * L + 7 * k + int(10 * p))
+    keys, nm, fr, off = make_batch(rng, 60, L, 40, err=0.06, n_frac=n_frac)
+    check_against_oracle(ctx, keys, nm, fr, off, L, k, p)
+
+
+@pytest.mark.parametrize("amf", [0, 1, 2, 1 << 30])
+def test_random_buckets_adjacency(ctx, amf):
+    rng = np.random.default_rng(900 + amf % 13)
+    keys, nm, fr, off = make_batch(rng, 50, 10, 40, err=0.08)
+    check_against_oracle(ctx, keys, nm, fr, off, 10, 1, algo=1, amf=amf)
+    check_against_oracle(ctx, keys, nm, fr, off, 10, 2, algo=1, amf=amf)
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    kept, root, st = ctx.dedup_batch(np.zeros(0, np.uint64), None, np.zeros(0, np.int32), [0], 12)
+    assert len(kept) == 0 and st["n_umis"] == 0
+    kept, _, _ = ctx.dedup_batch(np.zeros(0, np.uint64), None, np.zeros(0, np.int32),
+                                 [0, 0, 0], 12)
+    assert len(kept) == 0
+    # singleton buckets and empty buckets mixed
+    keys, nm = orc.encode_keys(["ACGTACGTACGT", "ACGTACGTACGA", "TTTTTTTTTTTT"])
+    kept, root, st = ctx.dedup_batch(keys, None, [1, 1, 4], [0, 0, 1, 2, 2, 3], 12)
+    assert kept.tolist() == [1, 1, 1] and root.tolist() == [0, 1, 2]
+    assert st["n_pairs"] == 0 and st["n_kept"] == 3
+
+
+def test_medium_bucket_crosses_tile_boundaries(ctx):
+    # one bucket larger than a 64-row chunk and a 1024-column LDS tile, dense in dist-1 pairs
+    rng = np.random.default_rng(42)
+    keys, nm, fr, off = make_batch(rng, 1, 7, 1500, err=0.1, mean_copies=2.0)
+    assert 1024 < len(keys) < 20000
+    check_against_oracle(ctx, keys, nm, fr, off, 7, 1)
+    # several such buckets next to small ones
+    keys, nm, fr, off = make_batch(rng, 6, 8, 900, err=0.05)
+    check_against_oracle(ctx, keys, nm, fr, off, 8, 2)
+
+
+def test_big_tile_kernel_on_all_sizes(ctx):
+    """small_max=0 sends every bucket through the 2048-row tile kernel."""
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    c.set_option("small_max", 0)
+    try:
+        rng = np.random.default_rng(43)
+        keys, nm, fr, off = make_batch(rng, 40, 12, 60, err=0.05, n_frac=0.01)
+        check_against_oracle(c, keys, nm, fr, off, 12, 1)
+        keys, nm, fr, off = make_batch(rng, 2, 7, 2500, err=0.08, mean_copies=2.0)
+        assert np.diff(off.astype(np.int64)).max() > 2048
+        check_against_oracle(c, keys, nm, fr, off, 7, 1)
+        keys, nm, fr, off = make_batch(rng, 2, 20, 1500, err=0.03)
+        check_against_oracle(c, keys, nm, fr, off, 20, 2)
+    finally:
+        c.close()
+
+
+def test_large_single_bucket_both_kernels(ctx):
+    """~20k unique 9-mers at one position (7.6% of the 4^9 space: chains and a giant
+    component).  Oracle needs a few seconds."""
+    rng = np.random.default_rng(44)
+    L = 9
+    raw = rng.integers(0, 4, (22000, L))
+    uniq = {"".join("ACGT"[c] for c in r) for r in raw}
+    umis = sorted(uniq)
+    rng.shuffle(umis)
+    freq = np.minimum(rng.geometric(0.6, len(umis)), 50).tolist()
+    umis, freq, _ = canonical(umis, freq)
+    keys, nm = orc.encode_keys(umis)
+    off = np.array([0, len(umis)], np.uint64)
+    st = check_against_oracle(ctx, keys, nm, np.array(freq, np.int32), off, L, 1)
+    assert st["n_edges"] > 0 and st["n_rounds"] >= 2
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    c.set_option("small_max", 1 << 20)  # same bucket through the wave-per-chunk kernel
+    try:
+        check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
+    finally:
+        c.close()
+
+
+def test_edge_list_overflow_is_transparent():
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    c.set_option("edge_capacity", 8)
+    try:
+        rng = np.random.default_rng(45)
+        keys, nm, fr, off = make_batch(rng, 30, 8, 60, err=0.1)
+        st = check_against_oracle(c, keys, nm, fr, off, 8, 2)
+        assert st["n_edges"] > 8
+    finally:
+        c.close()
+
+
+def test_contract_violations_are_reported(ctx):
+    import umi_collapse_rs_amd as umi
+    from umi_collapse_rs_amd import _lib
+    keys, nm = orc.encode_keys(["AAAA", "AAAT", "CCCC"])
+    with pytest.raises(umi.UmiHipError) as e:  # not freq-descending inside the bucket
+        ctx.dedup_batch(keys, None, [1, 2, 1], [0, 3], 4)
+    assert e.value.code == _lib.UMI_ERR_ORDER
+    with pytest.raises(umi.UmiHipError) as e:  # freq 0
+        ctx.dedup_batch(keys, None, [1, 1, 0], [0, 3], 4)
+    assert e.value.code == _lib.UMI_ERR_ORDER
+    # a rise in freq exactly at a bucket boundary is fine
+    kept, _, _ = ctx.dedup_batch(keys, None, [1, 2, 1], [0, 1, 3], 4)
+    assert kept.tolist() == [1, 1, 1]
+    for bad in (dict(umi_len=0), dict(umi_len=22), dict(k=-1), dict(algo=7)):
+        args = dict(umi_len=4, k=1, algo=0)
+        args.update(bad)
+        with pytest.raises(umi.UmiHipError) as e:
+            ctx.dedup_batch(keys, None, [1, 1, 1], [0, 3], args["umi_len"], args["k"], 0.5,
+                            args["algo"])
+        assert e.value.code == _lib.UMI_ERR_ARG
+
+
+def test_device_pointer_entry_point(ctx):
+    import torch
+    rng = np.random.default_rng(46)
+    keys, nm, fr, off = make_batch(rng, 40, 12, 50, err=0.05, n_frac=0.01)
+    dev = torch.device("cuda:0")
+    t_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+    t_nm = torch.from_numpy(nm.view(np.int64)).to(dev)
+    t_fr = torch.from_numpy(fr).to(dev)
+    t_kept = torch.zeros(len(keys), dtype=torch.uint8, device=dev)
+    t_root = torch.zeros(len(keys), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    st = ctx.dedup_batch_device(t_keys.data_ptr(), t_nm.data_ptr(), t_fr.data_ptr(), off, 12,
+                                t_kept.data_ptr(), t_root.data_ptr(), k=1, stream=stream)
+    torch.cuda.synchronize()
+    okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, 12, 1)
+    assert (t_kept.cpu().numpy() == okept).all()
+    assert (t_root.cpu().numpy().view(np.uint32) == oroot).all()
+    assert st["n_kept"] == int(okept.sum())

@@ -1,0 +1,648 @@
+// Host side of libumihip.so: context, work planning, the C ABI of include/umihip.h.
+// The product path has no CPU fallback: every entry point that computes needs the
+// gfx950 kernels in this same library and a live HIP device.
+#include "../../include/umihip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "umihip_internal.h"
+
+using namespace umihip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(UMI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return UMI_OK;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return fail(UMI_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(e == hipErrorOutOfMemory ? UMI_ERR_NOMEM : UMI_ERR_HIP,
+                        "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return UMI_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct Plan {
+    std::vector<PairTask> small_tasks, big_tasks;
+    uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
+};
+
+constexpr int MAX_ROUNDS_PER_SYNC = 4;
+constexpr int MAX_ROUNDS = 1 << 20;
+constexpr uint32_t BIG_COL_CHUNK = 16 * COL_TILE; // columns per big task
+
+} // namespace
+
+struct umi_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    bool profile = false;
+    uint64_t edge_capacity = 1u << 20;
+    uint32_t small_max = 1024;
+    // workspace
+    DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
+    // staging for the host-buffer entry point
+    DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
+    unsigned long long *h_counters = nullptr; // pinned
+    uint32_t *h_changed = nullptr;            // pinned
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, Plan &pl)
+{
+    pl.small_tasks.clear();
+    pl.big_tasks.clear();
+    pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = 0;
+    for (uint64_t b = 0; b < n_buckets; b++) {
+        const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
+        const uint64_t n = e - s;
+        pl.max_bucket = std::max(pl.max_bucket, n);
+        if (n < 2) continue;
+        pl.n_pairs += n * (n - 1) / 2;
+        if (n <= small_max) {
+            for (uint64_t r0 = s; r0 < e; r0 += SMALL_ROWS) {
+                pl.small_tasks.push_back({(uint32_t)r0, (uint32_t)e, (uint32_t)r0, (uint32_t)e});
+                pl.n_pairs_eval += (uint64_t)SMALL_ROWS * (((e - r0) + 31) / 32 * 32);
+            }
+        } else {
+            for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
+                for (uint64_t c0 = r0; c0 < e; c0 += BIG_COL_CHUNK) {
+                    const uint64_t c1 = std::min<uint64_t>(e, c0 + BIG_COL_CHUNK);
+                    pl.big_tasks.push_back(
+                        {(uint32_t)r0, (uint32_t)e, (uint32_t)c0, (uint32_t)c1});
+                    pl.n_pairs_eval += (uint64_t)BIG_ROWS * (((c1 - c0) + 31) / 32 * 32);
+                }
+            }
+        }
+    }
+}
+
+int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
+                 int algo, uint64_t *n_out)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!bucket_off) return fail(UMI_ERR_ARG, "bucket_off is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
+        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (k < 0) return fail(UMI_ERR_ARG, "k must be >= 0 (got %d)", k);
+    if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
+        return fail(UMI_ERR_ARG, "unknown algo %d", algo);
+    for (uint64_t b = 0; b < n_buckets; b++)
+        if (bucket_off[b + 1] < bucket_off[b])
+            return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu",
+                        (unsigned long long)b);
+    const uint64_t n = n_buckets ? bucket_off[n_buckets] : 0;
+    if (n_buckets && bucket_off[0] != 0) return fail(UMI_ERR_ARG, "bucket_off[0] must be 0");
+    if (n >= 0xFFFFFFF0ull)
+        return fail(UMI_ERR_ARG, "%llu entries exceed the 32-bit index space of one call",
+                    (unsigned long long)n);
+    *n_out = n;
+    return UMI_OK;
+}
+
+// The device pipeline shared by both batched entry points and by umi_data_new.
+// mode MODE_NEIGHBOURS stops after the pair kernels (edges hold the neighbour pairs).
+int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                 const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
+                 int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
+                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    umi_stats st;
+    memset(&st, 0, sizeof(st));
+    st.n_umis = n;
+    st.n_buckets = n_buckets;
+
+    const bool key32 = umi_len <= 16;
+    const bool need_pairs =
+        !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
+    Plan pl;
+    build_plan(bucket_off, n_buckets, ctx->small_max, pl);
+    st.max_bucket = pl.max_bucket;
+    st.n_pairs = pl.n_pairs;
+    if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
+
+    int rc;
+    if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
+        (rc = ctx->label.reserve((size_t)n * 4)) ||
+        (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
+        (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
+        (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
+        return rc;
+    const size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size();
+    if ((rc = ctx->tasks.reserve(std::max<size_t>(1, n_tasks) * sizeof(PairTask)))) return rc;
+    if (mode == MODE_ADJACENCY && need_pairs)
+        if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
+
+    unsigned long long *d_cnt = ctx->counters.as<unsigned long long>();
+    hipEvent_t *ev = ctx->ev;
+    const bool prof = ctx->profile;
+
+    if (prof) HIP_TRY(hipEventRecord(ev[0], s));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_tasks) {
+        PairTask *d_tasks = ctx->tasks.as<PairTask>();
+        if (!pl.small_tasks.empty())
+            HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
+                                   pl.small_tasks.size() * sizeof(PairTask),
+                                   hipMemcpyHostToDevice, s));
+        if (!pl.big_tasks.empty())
+            HIP_TRY(hipMemcpyAsync(d_tasks + pl.small_tasks.size(), pl.big_tasks.data(),
+                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice,
+                                   s));
+    }
+    HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
+                        percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
+                        ctx->label.as<uint32_t>(), d_cnt, s));
+    if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+
+    uint64_t n_edges = 0;
+    uint32_t cap_used = 0;
+    if (need_pairs && n_tasks) {
+        uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
+        for (int attempt = 0;; attempt++) {
+            if (cap > 0xFFFFFFF0ull) return fail(UMI_ERR_NOMEM, "edge list too large");
+            if ((rc = ctx->edges.reserve(cap * sizeof(uint2)))) return rc;
+            if (mode == MODE_NEIGHBOURS && (rc = ctx->edge_dist.reserve(cap))) return rc;
+            PairArgs a;
+            a.keys = d_keys;
+            a.nmask = d_nmask;
+            a.freq = d_freq;
+            a.thr = ctx->thr.as<int32_t>();
+            a.fkey = ctx->fkey.p;
+            a.edges = ctx->edges.as<uint2>();
+            a.edge_dist = ctx->edge_dist.as<uint8_t>();
+            a.counters = d_cnt;
+            a.edge_cap = (uint32_t)cap;
+            cap_used = (uint32_t)cap;
+            a.k = k;
+            a.mode = mode;
+            a.adj_max_freq = adj_max_freq;
+            a.tasks = ctx->tasks.as<PairTask>();
+            HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
+            a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
+            HIP_TRY(launch_pairs(a, (uint32_t)pl.big_tasks.size(), true, key32, s));
+            st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
+            if (prof) HIP_TRY(hipEventRecord(ev[2], s));
+            HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->h_counters[CNT_ERROR])
+                return fail(UMI_ERR_ORDER,
+                            "%llu entries break the input contract (freq < 1 or not in "
+                            "freq-descending rank order inside a bucket)",
+                            ctx->h_counters[CNT_ERROR]);
+            n_edges = ctx->h_counters[CNT_EDGES];
+            st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
+            if (n_edges <= cap) break;
+            if (attempt >= 2) return fail(UMI_ERR_HIP, "edge list overflow persists");
+            // overflow: the exact count is known now; redo the pair pass with room for it
+            cap = n_edges + n_edges / 16 + 1024;
+            ctx->edge_capacity = cap;
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
+        }
+    } else if (prof) {
+        HIP_TRY(hipEventRecord(ev[2], s));
+    }
+    st.n_edges = n_edges;
+
+    if (mode == MODE_NEIGHBOURS) {
+        if (!need_pairs || !n_tasks) {
+            HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->h_counters[CNT_ERROR])
+                return fail(UMI_ERR_ORDER, "freq < 1 in the umi_freq map");
+        }
+        if (stats) *stats = st;
+        return UMI_OK;
+    }
+
+    // ---- collapse
+    if (mode == MODE_DIRECTIONAL || !need_pairs) {
+        if (n_edges) {
+            uint32_t *d_changed = ctx->changed.as<uint32_t>();
+            int rounds = 0;
+            for (;;) {
+                HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
+                for (int r = 0; r < MAX_ROUNDS_PER_SYNC; r++)
+                    HIP_TRY(launch_prop_round(ctx->edges.as<uint2>(), d_cnt, cap_used,
+                                              ctx->label.as<uint32_t>(), n, d_changed, r,
+                                              (uint32_t)n_edges, s));
+                HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed,
+                                       sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC,
+                                       hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                bool done = false;
+                for (int r = 0; r < MAX_ROUNDS_PER_SYNC; r++) {
+                    rounds++;
+                    if (ctx->h_changed[r] == 0) {
+                        done = true;
+                        break;
+                    }
+                }
+                if (done) break;
+                if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
+            }
+            st.n_rounds = (uint32_t)rounds;
+        }
+        if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+        HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+    } else {
+        // adjacency with max_freq >= 1
+        uint8_t *d_status = ctx->status.as<uint8_t>();
+        uint8_t *d_blocked = ctx->blocked.as<uint8_t>();
+        HIP_TRY(hipMemsetAsync(d_status, 0, n, s));
+        HIP_TRY(hipMemsetAsync(d_blocked, 0, n, s));
+        int iters = 0;
+        for (;;) {
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UNKNOWN], 0, sizeof(unsigned long long), s));
+            HIP_TRY(launch_adj_iter(ctx->edges.as<uint2>(), d_cnt, cap_used, d_status, d_blocked, ctx->label.as<uint32_t>(), n, d_cnt,
+                                    (uint32_t)n_edges, s));
+            HIP_TRY(hipMemcpyAsync(&ctx->h_counters[CNT_UNKNOWN], &d_cnt[CNT_UNKNOWN],
+                                   sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            iters++;
+            if (ctx->h_counters[CNT_UNKNOWN] == 0) break;
+            if (iters > MAX_ROUNDS) return fail(UMI_ERR_HIP, "adjacency collapse diverged");
+        }
+        st.n_rounds = (uint32_t)iters;
+        if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt,
+                                    s));
+    }
+    if (prof) HIP_TRY(hipEventRecord(ev[4], s));
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ctx->h_counters[CNT_ERROR])
+        return fail(UMI_ERR_ORDER,
+                    "%llu entries break the input contract (freq < 1 or not in freq-descending "
+                    "rank order inside a bucket)",
+                    ctx->h_counters[CNT_ERROR]);
+    st.n_kept = ctx->h_counters[CNT_KEPT];
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&st.ms_prep, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&st.ms_collapse, ev[2], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
+        HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
+    }
+    if (stats) *stats = st;
+    return UMI_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *umi_last_error(void) { return g_err.c_str(); }
+
+int umi_abi_version(void) { return 1; }
+
+int umi_ctx_create(int device_id, umi_ctx **out)
+{
+    if (!out) return fail(UMI_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(UMI_ERR_NODEV, "no HIP device visible (%s)",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n_dev)
+        return fail(UMI_ERR_ARG, "device_id %d outside 0..%d", device_id, n_dev - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(UMI_ERR_NODEV, "device %d is %s; this library carries gfx950 code only",
+                    device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    umi_ctx *ctx = new (std::nothrow) umi_ctx();
+    if (!ctx) return fail(UMI_ERR_NOMEM, "out of host memory");
+    ctx->device = device_id;
+    hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (err == hipSuccess)
+        err = hipHostMalloc((void **)&ctx->h_counters, CNT_COUNT * sizeof(unsigned long long));
+    if (err == hipSuccess)
+        err = hipHostMalloc((void **)&ctx->h_changed, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1));
+    for (int i = 0; i < 6 && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
+    if (err != hipSuccess) {
+        umi_ctx_destroy(ctx);
+        return fail(UMI_ERR_HIP, "context setup failed: %s", hipGetErrorString(err));
+    }
+    *out = ctx;
+    return UMI_OK;
+}
+
+void umi_ctx_destroy(umi_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    DevBuf *bufs[] = {&ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
+                      &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
+                      &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
+                      &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
+    for (int i = 0; i < 6; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(UMI_ERR_ARG, "ctx/name is NULL");
+    if (!strcmp(name, "profile")) {
+        ctx->profile = value != 0;
+    } else if (!strcmp(name, "edge_capacity")) {
+        if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
+        ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "small_max")) {
+        if (value < 0) return fail(UMI_ERR_ARG, "small_max must be >= 0");
+        ctx->small_max = (uint32_t)std::min<int64_t>(value, 1 << 30);
+    } else {
+        return fail(UMI_ERR_ARG, "unknown option '%s'", name);
+    }
+    return UMI_OK;
+}
+
+int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys, uint64_t *nmask)
+{
+    if ((!ascii && n) || !keys) return fail(UMI_ERR_ARG, "ascii/keys is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
+        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    // code table of src/utils/read.rs:23-31; 0xFF = the reference panics
+    uint8_t code[256];
+    memset(code, 0xFF, sizeof(code));
+    code['A'] = 0x0; code['T'] = 0x5; code['C'] = 0x6; code['G'] = 0x3; code['N'] = 0x4;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint8_t *s = ascii + i * (uint64_t)umi_len;
+        uint64_t key = 0, nm = 0;
+        for (int b = 0; b < umi_len; b++) {
+            const uint8_t c = code[s[b]];
+            if (c == 0xFF)
+                return fail(UMI_ERR_CHAR, "Unknown character in UMI sequence: %u (UMI %llu)",
+                            (unsigned)s[b], (unsigned long long)i);
+            key |= (uint64_t)c << (3 * b);
+            if (c == 0x4) nm |= (uint64_t)0x7 << (3 * b);
+        }
+        keys[i] = key;
+        if (nmask) nmask[i] = nm;
+    }
+    return UMI_OK;
+}
+
+int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                           const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets,
+                           int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
+                           uint8_t *d_kept, uint32_t *d_root, void *hip_stream, umi_stats *stats)
+{
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    if (rc) return rc;
+    if (n && (!d_keys || !d_freq || !d_kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    if (n == 0) {
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->n_buckets = n_buckets;
+        }
+        return UMI_OK;
+    }
+    return run_pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len,
+                        k, percentage,
+                        algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
+                        adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats);
+}
+
+int umi_dedup_batch(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
+                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
+                    umi_stats *stats)
+{
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    if (rc) return rc;
+    if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    if (n == 0) {
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->n_buckets = n_buckets;
+        }
+        return UMI_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in_keys.reserve(n * 8)) || (rc = ctx->in_freq.reserve(n * 4)) ||
+        (rc = ctx->out_kept.reserve(n)) || (rc = ctx->out_root.reserve(n * 4)))
+        return rc;
+    if (nmask && (rc = ctx->in_nmask.reserve(n * 8))) return rc;
+    hipStream_t s = ctx->own_stream;
+    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
+    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, n * 8, hipMemcpyHostToDevice, s));
+    rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
+                      nmask ? ctx->in_nmask.as<uint64_t>() : nullptr, ctx->in_freq.as<int32_t>(),
+                      bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
+                      algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
+                      adj_max_freq, ctx->out_kept.as<uint8_t>(),
+                      root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
+    if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return UMI_OK;
+}
+
+} // extern "C"
+
+// ---- per-bucket DataStruct path ------------------------------------------------
+struct umi_data {
+    umi_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    int max_edits = 0;
+    std::vector<int32_t> freq;
+    std::vector<uint8_t> present;
+    // CSR of neighbours with dist <= max_edits (both directions), sorted by index
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> nbr;
+    std::vector<uint8_t> nbr_dist;
+};
+
+extern "C" {
+
+int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                 uint32_t n, int umi_len, int max_edits, umi_data **out)
+{
+    if (!out) return fail(UMI_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (n && (!keys || !freq)) return fail(UMI_ERR_ARG, "keys/freq is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
+        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (max_edits < 0) return fail(UMI_ERR_ARG, "max_edits must be >= 0");
+    std::unique_ptr<umi_data> d(new (std::nothrow) umi_data());
+    if (!d) return fail(UMI_ERR_NOMEM, "out of host memory");
+    d->ctx = ctx;
+    d->n = n;
+    d->max_edits = max_edits;
+    d->freq.assign(freq, freq + n);
+    d->present.assign(n, 1);
+    d->off.assign((size_t)n + 1, 0);
+    if (n >= 2) {
+        int rc;
+        HIP_TRY(hipSetDevice(ctx->device));
+        if ((rc = ctx->in_keys.reserve((size_t)n * 8)) || (rc = ctx->in_freq.reserve((size_t)n * 4)) ||
+            (nmask && (rc = ctx->in_nmask.reserve((size_t)n * 8))))
+            return rc;
+        hipStream_t s = ctx->own_stream;
+        // the neighbour build ignores freq and order; feed ones so that prep's
+        // contract check (rank order) does not apply to an unordered map
+        std::vector<int32_t> ones(n, 1);
+        hipError_t e = hipMemcpyAsync(ctx->in_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ctx->in_freq.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && nmask)
+            e = hipMemcpyAsync(ctx->in_nmask.p, nmask, (size_t)n * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s); // `ones` must outlive the copy
+        if (e != hipSuccess) return fail(UMI_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+        const uint64_t boff[2] = {0, n};
+        umi_stats st;
+        rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
+                          nmask ? ctx->in_nmask.as<uint64_t>() : nullptr,
+                          ctx->in_freq.as<int32_t>(), boff, 1, n, umi_len, max_edits, 0.0f,
+                          MODE_NEIGHBOURS, 0, nullptr, nullptr, s, &st);
+        if (rc) return rc;
+        const size_t E = (size_t)st.n_edges;
+        std::vector<uint2> pairs(E);
+        std::vector<uint8_t> pd(E);
+        if (E) {
+            e = hipMemcpy(pairs.data(), ctx->edges.p, E * sizeof(uint2), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(pd.data(), ctx->edge_dist.p, E, hipMemcpyDeviceToHost);
+            if (e != hipSuccess)
+                return fail(UMI_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+        }
+        for (size_t i = 0; i < E; i++) {
+            d->off[pairs[i].x + 1]++;
+            d->off[pairs[i].y + 1]++;
+        }
+        for (uint32_t i = 0; i < n; i++) d->off[i + 1] += d->off[i];
+        d->nbr.resize(2 * E);
+        d->nbr_dist.resize(2 * E);
+        std::vector<uint64_t> fill(d->off.begin(), d->off.end() - 1);
+        for (size_t i = 0; i < E; i++) {
+            uint64_t pa = fill[pairs[i].x]++, pb = fill[pairs[i].y]++;
+            d->nbr[pa] = pairs[i].y; d->nbr_dist[pa] = pd[i];
+            d->nbr[pb] = pairs[i].x; d->nbr_dist[pb] = pd[i];
+        }
+        // ascending neighbour index inside each row (the device appends in arrival order)
+        std::vector<std::pair<uint32_t, uint8_t>> tmp;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t a = d->off[i], b = d->off[i + 1];
+            tmp.clear();
+            for (uint64_t t = a; t < b; t++) tmp.emplace_back(d->nbr[t], d->nbr_dist[t]);
+            std::sort(tmp.begin(), tmp.end());
+            for (uint64_t t = a; t < b; t++) {
+                d->nbr[t] = tmp[t - a].first;
+                d->nbr_dist[t] = tmp[t - a].second;
+            }
+        }
+    }
+    *out = d.release();
+    return UMI_OK;
+}
+
+int umi_data_remove_near(umi_data *d, uint32_t query, int k, int32_t max_freq, uint32_t *out_idx,
+                         uint32_t *out_n)
+{
+    if (!d || !out_n || (!out_idx && d->n)) return fail(UMI_ERR_ARG, "NULL argument");
+    if (query >= d->n) return fail(UMI_ERR_ARG, "query %u outside 0..%u", query, d->n);
+    if (k > d->max_edits)
+        return fail(UMI_ERR_ARG, "k %d exceeds max_edits %d given to umi_data_new", k, d->max_edits);
+    // naive.rs:29-37 over the precomputed neighbour row; merge the query itself
+    // (dist 0, removed whatever its freq) in index order
+    uint32_t cnt = 0;
+    bool self_done = false;
+    auto emit_self = [&]() {
+        if (!self_done && k >= 0 && d->present[query]) {
+            d->present[query] = 0;
+            out_idx[cnt++] = query;
+        }
+        self_done = true;
+    };
+    for (uint64_t t = d->off[query]; t < d->off[query + 1]; t++) {
+        const uint32_t o = d->nbr[t];
+        if (o > query) emit_self();
+        if (d->present[o] && (int)d->nbr_dist[t] <= k &&
+            (d->nbr_dist[t] == 0 || d->freq[o] <= max_freq)) {
+            d->present[o] = 0;
+            out_idx[cnt++] = o;
+        }
+    }
+    emit_self();
+    *out_n = cnt;
+    return UMI_OK;
+}
+
+int umi_data_contains(const umi_data *d, uint32_t idx)
+{
+    if (!d) return fail(UMI_ERR_ARG, "d is NULL");
+    if (idx >= d->n) return fail(UMI_ERR_ARG, "idx %u outside 0..%u", idx, d->n);
+    return d->present[idx] ? 1 : 0;
+}
+
+void umi_data_free(umi_data *d) { delete d; }
+
+} // extern "C"

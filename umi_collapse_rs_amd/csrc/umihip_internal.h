@@ -1,0 +1,86 @@
+// Internal interface between the host side (umihip_api.cpp) and the gfx950
+// kernels (umihip_kernels.hip).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace umihip {
+
+// One unit of all-pairs work: rows [row0, min(row0 + tile_rows, row_end)) against
+// columns [col0, col1), all global entry indices of one bucket.  Only pairs with
+// row < col are reported, so a task whose column range starts at row0 covers
+// the diagonal tile.
+struct PairTask {
+    uint32_t row0;
+    uint32_t row_end;
+    uint32_t col0;
+    uint32_t col1;
+};
+
+enum PairMode : int {
+    MODE_DIRECTIONAL = 0, // directed edges u->v with freq[v] <= thr[u]   (directional.rs:38-39)
+    MODE_ADJACENCY = 1,   // forward edges u->v (u<v) with freq[v] <= max_freq (adjacency.rs:56)
+    MODE_NEIGHBOURS = 2,  // undirected (i<j, dist) lists for the DataStruct path
+};
+
+enum Counter : int {
+    CNT_EDGES = 0,      // directed edges appended (may exceed capacity: overflow)
+    CNT_CANDIDATES = 1, // filter hits that reached the exact check
+    CNT_ERROR = 2,      // prep validation failures
+    CNT_KEPT = 3,       // survivors
+    CNT_UNKNOWN = 4,    // adjacency collapse: undecided entries
+    CNT_COUNT = 8,
+};
+
+struct PairArgs {
+    const uint64_t *keys;
+    const uint64_t *nmask; // may be null
+    const int32_t *freq;
+    const int32_t *thr;
+    const void *fkey; // uint32_t[N] (2 bits/base, umi_len <= 16) or uint64_t[N]
+    const PairTask *tasks;
+    uint2 *edges;
+    uint8_t *edge_dist; // MODE_NEIGHBOURS only
+    unsigned long long *counters;
+    uint32_t edge_cap;
+    int k;
+    int mode;
+    int32_t adj_max_freq;
+};
+
+// tile geometry of the two pair kernels (rows per block)
+constexpr int SMALL_THREADS = 64;
+constexpr int SMALL_RPT = 1;
+constexpr int BIG_THREADS = 256;
+constexpr int BIG_RPT = 8;
+constexpr int SMALL_ROWS = SMALL_THREADS * SMALL_RPT;
+constexpr int BIG_ROWS = BIG_THREADS * BIG_RPT;
+constexpr int COL_TILE = 1024; // column keys staged in LDS per step
+
+hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                       const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len,
+                       float percentage, bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       unsigned long long *counters, hipStream_t s);
+
+hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);
+
+// one label-propagation round (hook over edges + pointer jump); round r is a
+// no-op on the device when round r-1 changed nothing.
+hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *counters,
+                             uint32_t edge_cap, uint32_t *label, uint32_t n, uint32_t *changed,
+                             int round, uint32_t n_edges_hint, hipStream_t s);
+
+hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
+                           unsigned long long *counters, hipStream_t s);
+
+// adjacency collapse with max_freq > 0 (greedy in rank order): one iteration
+hipError_t launch_adj_iter(const uint2 *edges, const unsigned long long *counters,
+                           uint32_t edge_cap, uint8_t *status, uint8_t *blocked, uint32_t *label,
+                           uint32_t n, unsigned long long *counters_rw, uint32_t n_edges_hint,
+                           hipStream_t s);
+hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, uint32_t n,
+                               uint8_t *kept, uint32_t *root, unsigned long long *counters,
+                               hipStream_t s);
+
+} // namespace umihip

@@ -1,0 +1,399 @@
+// gfx950 (MI355X / CDNA4) kernels of the UMI-collapse hot path.
+//
+// What they replace in the reference (tkob-vh/umi-collapse-rs):
+//   pair_kernel      Naive::remove_near's linear scans (src/data/naive.rs:26-40) with the
+//                    XOR-popcount distance of BitSet::bit_count_xor / umi_dist
+//                    (src/utils/bitset.rs:77-91, src/utils/mod.rs:24-26), evaluated for all
+//                    pairs of a bucket at once instead of row by row.
+//   hook/jump        Directional::visit_and_remove + the root loop
+//                    (src/algo/directional.rs:30-54,78-88) as a directed min-rank label
+//                    fixed point: survivor(v) <=> no entry of smaller rank reaches v.
+//   adj_*            Adjacency::apply's root loop (src/algo/adjacency.rs:52-60).
+//
+// Integer/bitwise work on 64-lane wavefronts: v_xor + v_bcnt + v_min3 per pair on a
+// 2-bit-per-base filter key, column keys broadcast from an LDS tile, the exact
+// 5-symbol distance only on the rare filter hits.  No MFMA (nothing here is a
+// dense contraction).
+#include <hip/hip_runtime.h>
+
+#include "umihip_internal.h"
+
+namespace umihip {
+
+namespace {
+
+constexpr int CHECK_BLOCK = 32; // columns between two "any hit?" checks
+
+__device__ __forceinline__ int popc(uint32_t x) { return __builtin_popcount(x); }
+__device__ __forceinline__ int popc(uint64_t x) { return __builtin_popcountll(x); }
+
+// Padding keys for rows/columns past the end of a range.  They only have to be
+// unlikely to pass the filter: every hit is re-checked against the index range.
+template <typename KeyT> __device__ __forceinline__ KeyT pad_row();
+template <> __device__ __forceinline__ uint32_t pad_row<uint32_t>() { return 0xFFFFFFFFu; }
+template <> __device__ __forceinline__ uint64_t pad_row<uint64_t>() { return ~0ull; }
+template <typename KeyT> __device__ __forceinline__ KeyT pad_col();
+template <> __device__ __forceinline__ uint32_t pad_col<uint32_t>() { return 0x0F000000u; }
+template <> __device__ __forceinline__ uint64_t pad_col<uint64_t>() { return 0xF000000000000000ull; }
+
+// Rust `f32 as i32` (saturating, NaN -> 0) of percentage * (freq+1) as f32,
+// src/algo/directional.rs:38.
+__device__ __forceinline__ int32_t threshold_of(float percentage, int32_t freq)
+{
+    float prod = __fmul_rn(percentage, (float)(freq + 1));
+    if (prod != prod) return 0;
+    if (prod >= 2147483648.0f) return 2147483647;
+    if (prod <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)prod;
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ keys,
+                                                   const uint64_t *__restrict__ nmask,
+                                                   const int32_t *__restrict__ freq,
+                                                   const uint64_t *__restrict__ bucket_off,
+                                                   uint64_t n_buckets, uint32_t n, int umi_len,
+                                                   float percentage, int key32,
+                                                   void *__restrict__ fkey,
+                                                   int32_t *__restrict__ thr,
+                                                   uint32_t *__restrict__ label,
+                                                   unsigned long long *__restrict__ counters)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        const uint64_t nm = nmask ? nmask[i] : 0ull;
+        const int32_t f = freq[i];
+        thr[i] = threshold_of(percentage, f);
+        label[i] = i;
+        // filter key: N (100, masked by n_bits) folded onto A (000) so that the
+        // filter distance never exceeds the exact one.
+        const uint64_t k3 = key & ~nm;
+        if (key32) {
+            uint32_t fk = 0;
+            for (int b = 0; b < umi_len; b++) fk |= (uint32_t)((k3 >> (3 * b)) & 3ull) << (2 * b);
+            ((uint32_t *)fkey)[i] = fk;
+        } else {
+            ((uint64_t *)fkey)[i] = k3;
+        }
+        // contract check: freq >= 1, non-increasing inside a bucket
+        bool bad = f < 1;
+        if (i > 0 && f > freq[i - 1]) {
+            uint64_t lo = 0, hi = n_buckets; // largest b with bucket_off[b] <= i
+            while (lo < hi) {
+                uint64_t mid = (lo + hi + 1) >> 1;
+                if (bucket_off[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            if (bucket_off[lo] != i) bad = true;
+        }
+        if (bad) atomicAdd(&counters[CNT_ERROR], 1ull);
+    }
+}
+
+// Exact check of one filter hit, with the reference's arithmetic, and edge emission.
+// Cold path (a few hits per million pairs): kept out of line, arguments by value so
+// that the kernel's argument block stays in SGPRs.
+__device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
+                                         const uint64_t *__restrict__ nmask,
+                                         const int32_t *__restrict__ freq,
+                                         const int32_t *__restrict__ thr, uint2 *edges,
+                                         uint8_t *edge_dist, unsigned long long *counters,
+                                         uint32_t edge_cap, int k, int mode, int32_t adj_max_freq,
+                                         uint32_t row_end, uint32_t col1, uint32_t gi, uint32_t gj)
+{
+    if (gi >= row_end || gj >= col1 || gi >= gj) return;
+    atomicAdd(&counters[CNT_CANDIDATES], 1ull);
+    const uint64_t ka = keys[gi], kb = keys[gj];
+    const uint64_t na = nmask ? nmask[gi] : 0ull, nb = nmask ? nmask[gj] : 0ull;
+    const uint64_t x = na ^ nb;
+    // bitset.rs:85-87 (one word) and utils/mod.rs:25
+    const int bcx = __builtin_popcountll(x | (ka ^ kb)) - __builtin_popcountll(x) / 3;
+    const int dist = bcx / 2;
+    if (dist > k) return;
+    if (mode == MODE_NEIGHBOURS) {
+        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
+        if (pos < edge_cap) {
+            edges[pos] = make_uint2(gi, gj);
+            edge_dist[pos] = (uint8_t)dist;
+        }
+        return;
+    }
+    const int32_t fi = freq[gi], fj = freq[gj];
+    bool fwd, bwd;
+    if (mode == MODE_DIRECTIONAL) {
+        fwd = fj <= thr[gi]; // naive.rs:31 with max_freq = threshold(start) (directional.rs:38-39)
+        bwd = fi <= thr[gj];
+    } else {
+        fwd = fj <= adj_max_freq; // adjacency.rs:56
+        bwd = false;              // a root only ever sees entries of larger rank
+    }
+    if (fwd) {
+        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
+        if (pos < edge_cap) edges[pos] = make_uint2(gi, gj);
+    }
+    if (bwd) {
+        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
+        if (pos < edge_cap) edges[pos] = make_uint2(gj, gi);
+    }
+}
+
+// All pairs (row, col) of one task through the filter.  Each lane keeps RPT row
+// keys in registers; column keys are staged in LDS and read back as wave-wide
+// broadcasts (ds_read_b128, same address in every lane), so a pair costs one
+// v_xor, one v_bcnt and half a v_min3.
+template <typename KeyT, int THREADS, int RPT>
+__global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
+{
+    constexpr int VEC = 16 / (int)sizeof(KeyT);
+    __shared__ __attribute__((aligned(16))) KeyT cols[COL_TILE];
+    const PairTask *__restrict__ tp = a.tasks + blockIdx.x;
+    // wave-uniform task fields (SGPRs): every loop bound below is scalar
+    const uint32_t row0 = __builtin_amdgcn_readfirstlane(tp->row0);
+    const uint32_t row_end = __builtin_amdgcn_readfirstlane(tp->row_end);
+    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0);
+    const uint32_t col1 = __builtin_amdgcn_readfirstlane(tp->col1);
+    const KeyT *__restrict__ fkey = (const KeyT *)a.fkey;
+    const int tid = threadIdx.x;
+    const int lim = 2 * a.k;
+
+    KeyT rk[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const uint32_t gi = row0 + r * THREADS + tid;
+        rk[r] = gi < row_end ? fkey[gi] : pad_row<KeyT>();
+    }
+
+    for (uint32_t c0 = col0; c0 < col1; c0 += COL_TILE) {
+        const int nc = (int)min((uint32_t)COL_TILE, col1 - c0);
+        const int nc_pad = (nc + CHECK_BLOCK - 1) & ~(CHECK_BLOCK - 1);
+        __syncthreads();
+        for (int s = tid; s < nc_pad; s += THREADS) {
+            const uint32_t gj = c0 + s;
+            cols[s] = gj < col1 ? fkey[gj] : pad_col<KeyT>();
+        }
+        __syncthreads();
+        for (int cb = 0; cb < nc; cb += CHECK_BLOCK) {
+            int m[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; r++) m[r] = 255;
+#pragma unroll
+            for (int c = 0; c < CHECK_BLOCK; c += VEC) {
+                KeyT cv[VEC];
+                *reinterpret_cast<uint4 *>(cv) = *reinterpret_cast<const uint4 *>(&cols[cb + c]);
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+#pragma unroll
+                    for (int v = 0; v < VEC; v += 2) // -> v_min3_u32(m, p0, p1)
+                        m[r] = min(min(m[r], popc(rk[r] ^ cv[v])), popc(rk[r] ^ cv[v + 1]));
+                }
+            }
+            int mm = m[0];
+#pragma unroll
+            for (int r = 1; r < RPT; r++) mm = min(mm, m[r]);
+            if (__any(mm <= lim)) {
+                // rare: re-walk this block of columns, only for the row slots that hit
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    if (__any(m[r] <= lim)) {
+                        const uint32_t gi = row0 + r * THREADS + tid;
+                        for (int c = 0; c < CHECK_BLOCK; c++) {
+                            if (popc(rk[r] ^ cols[cb + c]) <= lim)
+                                verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist,
+                                            a.counters, a.edge_cap, a.k, a.mode, a.adj_max_freq,
+                                            row_end, col1, gi, c0 + cb + c);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- collapse: directed min-rank label propagation ---------------------------
+__global__ __launch_bounds__(256) void hook_kernel(const uint2 *__restrict__ edges,
+                                                   const unsigned long long *counters,
+                                                   uint32_t edge_cap, uint32_t *label,
+                                                   uint32_t *changed, int round)
+{
+    if (round > 0 && changed[round - 1] == 0) return;
+    unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    bool any = false;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const uint2 uv = edges[e];
+        const uint32_t lu = label[uv.x];
+        if (lu < label[uv.y]) {
+            atomicMin(&label[uv.y], lu);
+            any = true;
+        }
+    }
+    if (any) changed[round] = 1;
+}
+
+__global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, uint32_t *changed,
+                                                   int round)
+{
+    if (round > 0 && changed[round - 1] == 0) return;
+    bool any = false;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const uint32_t l = label[v];
+        if (l != v) {
+            // label[l] reaches l and l reaches v: transitivity keeps the invariant
+            const uint32_t ll = label[l];
+            if (ll < l) {
+                atomicMin(&label[v], ll);
+                any = true;
+            }
+        }
+    }
+    if (any) changed[round] = 1;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ label,
+                                                       uint32_t n, uint8_t *__restrict__ kept,
+                                                       uint32_t *__restrict__ root,
+                                                       unsigned long long *counters)
+{
+    unsigned int cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t l = label[i];
+        const bool kp = l == i;
+        kept[i] = kp ? 1 : 0;
+        if (root) root[i] = l;
+        cnt += kp ? 1u : 0u;
+    }
+    // wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[CNT_KEPT], (unsigned long long)cnt);
+}
+
+// ---- adjacency with max_freq > 0: greedy independent set in rank order --------
+constexpr uint8_t ST_UNKNOWN = 0, ST_ROOT = 1, ST_REMOVED = 2;
+
+__global__ __launch_bounds__(256) void adj_mark_kernel(const uint2 *__restrict__ edges,
+                                                       const unsigned long long *counters,
+                                                       uint32_t edge_cap, uint8_t *status,
+                                                       uint8_t *blocked, uint32_t *label)
+{
+    unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const uint2 uv = edges[e]; // u < v
+        const uint8_t su = status[uv.x];
+        if (su == ST_ROOT) {
+            status[uv.y] = ST_REMOVED; // the first root in rank order is the one that removes it
+            atomicMin(&label[uv.y], uv.x);
+        } else if (su == ST_UNKNOWN) {
+            blocked[uv.y] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adj_promote_kernel(uint8_t *status, uint8_t *blocked,
+                                                          uint32_t n,
+                                                          unsigned long long *counters)
+{
+    unsigned int unk = 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        if (status[v] == ST_UNKNOWN) {
+            if (!blocked[v]) status[v] = ST_ROOT; else unk++;
+        }
+        blocked[v] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) unk += __shfl_down(unk, off);
+    if ((threadIdx.x & 63) == 0 && unk) atomicAdd(&counters[CNT_UNKNOWN], (unsigned long long)unk);
+}
+
+__global__ __launch_bounds__(256) void adj_finalize_kernel(const uint8_t *__restrict__ status,
+                                                           const uint32_t *__restrict__ label,
+                                                           uint32_t n, uint8_t *__restrict__ kept,
+                                                           uint32_t *__restrict__ root,
+                                                           unsigned long long *counters)
+{
+    unsigned int cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const bool kp = status[i] == ST_ROOT;
+        kept[i] = kp ? 1 : 0;
+        if (root) root[i] = kp ? i : label[i];
+        cnt += kp ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[CNT_KEPT], (unsigned long long)cnt);
+}
+
+inline uint32_t grid_for(uint64_t work, int block, uint32_t cap = 2048)
+{
+    uint64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+} // namespace
+
+hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                       const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len,
+                       float percentage, bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       unsigned long long *counters, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    prep_kernel<<<grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, bucket_off, n_buckets, n,
+                                                 umi_len, percentage, key32 ? 1 : 0, fkey, thr,
+                                                 label, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s)
+{
+    if (n_tasks == 0) return hipSuccess;
+    if (big) {
+        if (key32)
+            pair_kernel<uint32_t, BIG_THREADS, BIG_RPT><<<n_tasks, BIG_THREADS, 0, s>>>(a);
+        else
+            pair_kernel<uint64_t, BIG_THREADS, BIG_RPT><<<n_tasks, BIG_THREADS, 0, s>>>(a);
+    } else {
+        if (key32)
+            pair_kernel<uint32_t, SMALL_THREADS, SMALL_RPT><<<n_tasks, SMALL_THREADS, 0, s>>>(a);
+        else
+            pair_kernel<uint64_t, SMALL_THREADS, SMALL_RPT><<<n_tasks, SMALL_THREADS, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *counters,
+                             uint32_t edge_cap, uint32_t *label, uint32_t n, uint32_t *changed,
+                             int round, uint32_t n_edges_hint, hipStream_t s)
+{
+    hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, label,
+                                                            changed, round);
+    jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(label, n, changed, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
+                           unsigned long long *counters, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    finalize_kernel<<<grid_for(n, 256), 256, 0, s>>>(label, n, kept, root, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_adj_iter(const uint2 *edges, const unsigned long long *counters,
+                           uint32_t edge_cap, uint8_t *status, uint8_t *blocked, uint32_t *label,
+                           uint32_t n, unsigned long long *counters_rw, uint32_t n_edges_hint,
+                           hipStream_t s)
+{
+    adj_mark_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, status,
+                                                                blocked, label);
+    adj_promote_kernel<<<grid_for(n, 256), 256, 0, s>>>(status, blocked, n, counters_rw);
+    return hipGetLastError();
+}
+
+hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, uint32_t n,
+                               uint8_t *kept, uint32_t *root, unsigned long long *counters,
+                               hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    adj_finalize_kernel<<<grid_for(n, 256), 256, 0, s>>>(status, label, n, kept, root, counters);
+    return hipGetLastError();
+}
+
+} // namespace umihip

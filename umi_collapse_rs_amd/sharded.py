@@ -1,0 +1,111 @@
+"""Multi-GPU driver: one process per GPU, alignment-position buckets sharded across
+ranks, kept-read mask reassembled with an all-gatherv (RCCL over xGMI when the
+process group is "nccl"; "gloo" in the CPU tests).
+
+Buckets are independent units (src/deduplicate_sam.rs:207-233 shares nothing between
+iterations but additive counters), so there is no data-path collective: the only
+exchange is the final mask gather."""
+import heapq
+
+import numpy as np
+
+
+def partition_buckets(sizes, world_size):
+    """Longest-processing-time assignment on cost n_b^2 (ties -> lower bucket index,
+    then lower rank).  Returns a list of ascending bucket-index arrays, one per rank.
+    Deterministic: every rank computes the same answer from the same sizes."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    cost = sizes.astype(np.float64) ** 2 + sizes  # + n: empty-ish buckets still cost a pass
+    order = np.lexsort((np.arange(len(sizes)), -cost))
+    heap = [(0.0, r) for r in range(world_size)]
+    heapq.heapify(heap)
+    owner = np.zeros(len(sizes), dtype=np.int64)
+    for b in order:
+        load, r = heapq.heappop(heap)
+        owner[b] = r
+        heapq.heappush(heap, (load + cost[b], r))
+    return [np.nonzero(owner == r)[0] for r in range(world_size)]
+
+
+def shard_arrays(keys, nmask, freq, bucket_off, buckets):
+    """Entries of the given buckets, concatenated in ascending bucket order.
+    Returns (keys, nmask, freq, local bucket_off, global entry index of each local entry)."""
+    bucket_off = np.asarray(bucket_off, dtype=np.int64)
+    s, e = bucket_off[buckets], bucket_off[buckets + 1]
+    n = e - s
+    loff = np.zeros(len(buckets) + 1, dtype=np.uint64)
+    loff[1:] = np.cumsum(n)
+    total = int(loff[-1])
+    if total:
+        gidx = np.repeat(s - loff[:-1].astype(np.int64), n) + np.arange(total)
+    else:
+        gidx = np.zeros(0, dtype=np.int64)
+    return (keys[gidx], None if nmask is None else nmask[gidx], freq[gidx], loff, gidx)
+
+
+def allgatherv_mask(local_bits, counts, dist, device=None):
+    """all-gatherv of bit-packed kept masks: every rank ends with all ranks' bytes.
+    local_bits: uint8 tensor (packed bits of this rank's slice), counts: bytes per rank.
+    Implemented as one all_gather on max-padded slices (RCCL has no native gatherv; the
+    payload is <= 1 bit per unique UMI, latency-bound: SURVEY.md 8e)."""
+    import torch
+    world = dist.get_world_size()
+    mx = max(1, int(max(counts)))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=local_bits.device)
+    buf[: local_bits.numel()] = local_bits
+    out = torch.empty(world * mx, dtype=torch.uint8, device=local_bits.device)
+    dist.all_gather_into_tensor(out, buf)
+    return [out[r * mx: r * mx + int(counts[r])] for r in range(world)]
+
+
+class ShardedDedup:
+    """Runs the batched hot path on this rank's buckets and gathers the global mask.
+
+    compute(keys, nmask, freq, bucket_off) -> kept uint8[n_local] is the per-GPU hot
+    path (default: Context.dedup_batch through libumihip.so; tests on CPU/gloo pass
+    the oracle here -- the product default never does)."""
+
+    def __init__(self, dist, compute):
+        self.dist = dist
+        self.compute = compute
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def run(self, keys, nmask, freq, bucket_off):
+        import torch
+        bucket_off = np.asarray(bucket_off, dtype=np.uint64)
+        sizes = np.diff(bucket_off.astype(np.int64))
+        parts = partition_buckets(sizes, self.world)
+        mine = parts[self.rank]
+        lk, lnm, lf, loff, gidx = shard_arrays(keys, nmask, freq, bucket_off, mine)
+        kept_local = np.asarray(self.compute(lk, lnm, lf, loff), dtype=np.uint8)
+        # slice sizes of every rank are known from the partition: no size exchange
+        n_local = [int(sizes[p].sum()) for p in parts]
+        counts = [(n + 7) // 8 for n in n_local]
+        backend = self.dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu"
+        bits = torch.from_numpy(np.packbits(kept_local, bitorder="little")).to(dev)
+        gathered = allgatherv_mask(bits, counts, self.dist)
+        kept = np.zeros(int(bucket_off[-1]), dtype=np.uint8)
+        for r in range(self.world):
+            if n_local[r] == 0:
+                continue
+            kr = np.unpackbits(gathered[r].cpu().numpy(), bitorder="little")[: n_local[r]]
+            kept[_global_index(bucket_off, parts[r])] = kr
+        # additive counters of deduplicate_sam.rs:217-219
+        tot = torch.tensor([int(kept_local.sum())], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(tot)
+        assert int(tot.item()) == int(kept.sum())
+        return kept
+
+
+def _global_index(bucket_off, buckets):
+    bucket_off = np.asarray(bucket_off, dtype=np.int64)
+    s, e = bucket_off[buckets], bucket_off[buckets + 1]
+    n = e - s
+    loff = np.zeros(len(buckets) + 1, dtype=np.int64)
+    loff[1:] = np.cumsum(n)
+    total = int(loff[-1])
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    return np.repeat(s - loff[:-1], n) + np.arange(total)
