@@ -60,6 +60,22 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+    Whichever copy is mapped first serves the whole process, and a process that starts on
+    the system copy cannot initialise torch.cuda afterwards.  So when torch is installed,
+    map its copy first; without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libumihip.so; raises if it has not been built (no silent fallback)."""
     global _lib
@@ -67,6 +83,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise UmiHipError(UMI_ERR_NODEV, "libumihip.so not built (run `make` or "
                               "__graft_entry__.build()); there is no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -88,6 +88,34 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
     }
 }
 
+// Per-block staging of emitted edges in LDS: one global atomic per flush instead of one
+// per edge (a single hot counter word saturates near 90 atomics/us on this chip).
+constexpr int EDGE_BUF = 512;
+struct EdgeStage {
+    uint2 e[EDGE_BUF];
+    uint8_t d[EDGE_BUF];
+    unsigned int count;      // edges staged (may run past EDGE_BUF: the excess went direct)
+    unsigned int candidates; // filter hits seen by this block
+    unsigned int base;       // flush: global position of e[0]
+};
+
+__device__ __forceinline__ void emit_edge(EdgeStage *st, uint2 *edges, uint8_t *edge_dist,
+                                          unsigned long long *counters, uint32_t edge_cap,
+                                          uint32_t u, uint32_t v, int dist, bool with_dist)
+{
+    const unsigned int slot = atomicAdd(&st->count, 1u);
+    if (slot < EDGE_BUF) {
+        st->e[slot] = make_uint2(u, v);
+        st->d[slot] = (uint8_t)dist;
+    } else { // stage full (a very dense tile): append directly
+        const unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
+        if (pos < edge_cap) {
+            edges[pos] = make_uint2(u, v);
+            if (with_dist) edge_dist[pos] = (uint8_t)dist;
+        }
+    }
+}
+
 // Exact check of one filter hit, with the reference's arithmetic, and edge emission.
 // Cold path (a few hits per million pairs): kept out of line, arguments by value so
 // that the kernel's argument block stays in SGPRs.
@@ -96,11 +124,12 @@ __device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
                                          const int32_t *__restrict__ freq,
                                          const int32_t *__restrict__ thr, uint2 *edges,
                                          uint8_t *edge_dist, unsigned long long *counters,
-                                         uint32_t edge_cap, int k, int mode, int32_t adj_max_freq,
-                                         uint32_t row_end, uint32_t col1, uint32_t gi, uint32_t gj)
+                                         EdgeStage *st, uint32_t edge_cap, int k, int mode,
+                                         int32_t adj_max_freq, uint32_t row_end, uint32_t col1,
+                                         uint32_t gi, uint32_t gj)
 {
     if (gi >= row_end || gj >= col1 || gi >= gj) return;
-    atomicAdd(&counters[CNT_CANDIDATES], 1ull);
+    atomicAdd(&st->candidates, 1u);
     const uint64_t ka = keys[gi], kb = keys[gj];
     const uint64_t na = nmask ? nmask[gi] : 0ull, nb = nmask ? nmask[gj] : 0ull;
     const uint64_t x = na ^ nb;
@@ -109,11 +138,7 @@ __device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
     const int dist = bcx / 2;
     if (dist > k) return;
     if (mode == MODE_NEIGHBOURS) {
-        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
-        if (pos < edge_cap) {
-            edges[pos] = make_uint2(gi, gj);
-            edge_dist[pos] = (uint8_t)dist;
-        }
+        emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, true);
         return;
     }
     const int32_t fi = freq[gi], fj = freq[gj];
@@ -125,14 +150,33 @@ __device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
         fwd = fj <= adj_max_freq; // adjacency.rs:56
         bwd = false;              // a root only ever sees entries of larger rank
     }
-    if (fwd) {
-        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
-        if (pos < edge_cap) edges[pos] = make_uint2(gi, gj);
+    if (fwd) emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, false);
+    if (bwd) emit_edge(st, edges, edge_dist, counters, edge_cap, gj, gi, dist, false);
+}
+
+// Block-wide: move the staged edges to the global list.  Called by every thread.
+template <int THREADS>
+__device__ __forceinline__ void flush_edges(EdgeStage *st, uint2 *edges, uint8_t *edge_dist,
+                                            unsigned long long *counters, uint32_t edge_cap,
+                                            bool with_dist)
+{
+    __syncthreads();
+    const unsigned int n = min(st->count, (unsigned int)EDGE_BUF);
+    if (n == 0) return; // uniform: count is stable between the two barriers
+    if (threadIdx.x == 0)
+        st->base = (unsigned int)min(atomicAdd(&counters[CNT_EDGES], (unsigned long long)n),
+                                     (unsigned long long)0xFFFFFFFFu);
+    __syncthreads();
+    const unsigned int base = st->base;
+    for (unsigned int i = threadIdx.x; i < n; i += THREADS) {
+        const unsigned long long pos = (unsigned long long)base + i;
+        if (pos < edge_cap) {
+            edges[pos] = st->e[i];
+            if (with_dist) edge_dist[pos] = st->d[i];
+        }
     }
-    if (bwd) {
-        unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
-        if (pos < edge_cap) edges[pos] = make_uint2(gj, gi);
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->count = 0;
 }
 
 // All pairs (row, col) of one task through the filter.  Each lane keeps RPT row
@@ -144,6 +188,7 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
 {
     constexpr int VEC = 16 / (int)sizeof(KeyT);
     __shared__ __attribute__((aligned(16))) KeyT cols[COL_TILE];
+    __shared__ EdgeStage stage;
     const PairTask *__restrict__ tp = a.tasks + blockIdx.x;
     // wave-uniform task fields (SGPRs): every loop bound below is scalar
     const uint32_t row0 = __builtin_amdgcn_readfirstlane(tp->row0);
@@ -153,6 +198,12 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
     const KeyT *__restrict__ fkey = (const KeyT *)a.fkey;
     const int tid = threadIdx.x;
     const int lim = 2 * a.k;
+    const bool with_dist = a.mode == MODE_NEIGHBOURS;
+
+    if (tid == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+    }
 
     KeyT rk[RPT];
 #pragma unroll
@@ -197,14 +248,18 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
                         for (int c = 0; c < CHECK_BLOCK; c++) {
                             if (popc(rk[r] ^ cols[cb + c]) <= lim)
                                 verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist,
-                                            a.counters, a.edge_cap, a.k, a.mode, a.adj_max_freq,
-                                            row_end, col1, gi, c0 + cb + c);
+                                            a.counters, &stage, a.edge_cap, a.k, a.mode,
+                                            a.adj_max_freq, row_end, col1, gi, c0 + cb + c);
                         }
                     }
                 }
             }
         }
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist);
     }
+    __syncthreads();
+    if (tid == 0 && stage.candidates)
+        atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
 }
 
 // ---- collapse: directed min-rank label propagation ---------------------------
