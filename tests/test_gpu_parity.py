@@ -105,20 +105,54 @@ def test_medium_bucket_crosses_tile_boundaries(ctx):
     check_against_oracle(ctx, keys, nm, fr, off, 8, 2)
 
 
-def test_big_tile_kernel_on_all_sizes(ctx):
-    """small_max=0 sends every bucket through the 2048-row tile kernel."""
+@pytest.mark.parametrize("bitslice", [1, 0])
+def test_tile_kernels_on_all_sizes(bitslice):
+    """small_max=0 sends every bucket through the tile kernels: the bit-sliced one
+    (bitslice=1, k<=3) or the popcount one (bitslice=0)."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
     c.set_option("small_max", 0)
+    c.set_option("bitslice", bitslice)
     try:
         rng = np.random.default_rng(43)
         keys, nm, fr, off = make_batch(rng, 40, 12, 60, err=0.05, n_frac=0.01)
-        check_against_oracle(c, keys, nm, fr, off, 12, 1)
+        for k in (0, 1, 2, 3, 4):
+            check_against_oracle(c, keys, nm, fr, off, 12, k)
         keys, nm, fr, off = make_batch(rng, 2, 7, 2500, err=0.08, mean_copies=2.0, exact=True)
         assert np.diff(off.astype(np.int64)).max() > 2048
         check_against_oracle(c, keys, nm, fr, off, 7, 1)
-        keys, nm, fr, off = make_batch(rng, 2, 20, 1500, err=0.03, exact=True)
+        check_against_oracle(c, keys, nm, fr, off, 7, 2, p=1.0)
+        keys, nm, fr, off = make_batch(rng, 2, 20, 1500, err=0.03, n_frac=0.01, exact=True)
         check_against_oracle(c, keys, nm, fr, off, 20, 2)
+        keys, nm, fr, off = make_batch(rng, 3, 21, 700, err=0.03, exact=True)
+        check_against_oracle(c, keys, nm, fr, off, 21, 3)
+        keys, nm, fr, off = make_batch(rng, 3, 16, 700, err=0.05, n_frac=0.02, exact=True)
+        check_against_oracle(c, keys, nm, fr, off, 16, 1)
+        keys, nm, fr, off = make_batch(rng, 5, 5, 300, err=0.1, exact=True)
+        check_against_oracle(c, keys, nm, fr, off, 5, 1)
+        check_against_oracle(c, keys, nm, fr, off, 5, 1, algo=1, amf=3)
+    finally:
+        c.close()
+
+
+def test_bitsliced_rows_beyond_one_tile_and_column_chunks():
+    """One bucket > 4096 rows (several 64-thread row tiles, diagonal and off-diagonal
+    tasks, more than one 4096-column chunk) against the oracle."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(47)
+    L = 8
+    raw = rng.integers(0, 4, (12000, L))
+    umis = sorted({"".join("ACGT"[c] for c in r) for r in raw})
+    rng.shuffle(umis)
+    freq = np.minimum(rng.geometric(0.5, len(umis)), 30).tolist()
+    umis, freq, _ = canonical(umis, freq)
+    assert len(umis) > 9000
+    keys, nm = orc.encode_keys(umis)
+    off = np.array([0, len(umis)], np.uint64)
+    c = umi.Context(0)
+    try:
+        st = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
+        assert st["n_pair_launches"] >= 2  # diagonal + off-diagonal bit-sliced launches
     finally:
         c.close()
 

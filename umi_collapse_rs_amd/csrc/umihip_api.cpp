@@ -73,7 +73,15 @@ struct DevBuf {
 
 struct Plan {
     std::vector<PairTask> small_tasks, big_tasks;
+    // bit-sliced tasks: [0] narrow diagonal, [1] narrow off-diagonal, [2] wide diag, [3] wide off
+    std::vector<BsTask> bs_tasks[4];
+    std::vector<PlaneTask> plane_tasks;
+    uint64_t plane_words = 0;
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
+    size_t n_bs() const
+    {
+        return bs_tasks[0].size() + bs_tasks[1].size() + bs_tasks[2].size() + bs_tasks[3].size();
+    }
 };
 
 constexpr int MAX_ROUNDS_PER_SYNC = 4;
@@ -88,8 +96,10 @@ struct umi_ctx {
     bool profile = false;
     uint64_t edge_capacity = 1u << 20;
     uint32_t small_max = 1024;
+    bool use_bitslice = true;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
+    DevBuf bs_tasks, plane_tasks, planes;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
     unsigned long long *h_counters = nullptr; // pinned
@@ -99,11 +109,17 @@ struct umi_ctx {
 
 namespace {
 
-void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, Plan &pl)
+void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
+                int umi_len, Plan &pl)
 {
     pl.small_tasks.clear();
     pl.big_tasks.clear();
+    for (auto &v : pl.bs_tasks) v.clear();
+    pl.plane_tasks.clear();
+    pl.plane_words = 0;
     pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = 0;
+    const uint32_t np = 2 * (uint32_t)bs_padded_len(umi_len);
+    const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
     for (uint64_t b = 0; b < n_buckets; b++) {
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
         const uint64_t n = e - s;
@@ -115,6 +131,26 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
                 pl.small_tasks.push_back({(uint32_t)r0, (uint32_t)e, (uint32_t)r0, (uint32_t)e});
                 pl.n_pairs_eval += (uint64_t)SMALL_ROWS * (((e - r0) + 31) / 32 * 32);
             }
+        } else if (use_bs) {
+            const uint32_t ngroups = (uint32_t)((n + 31) / 32);
+            const bool wide = n >= (uint64_t)BS_WIDE_MIN;
+            const uint32_t tile_groups = (wide ? 256u : 64u) * gpl;
+            for (uint32_t g = 0; g < ngroups; g += 2)
+                pl.plane_tasks.push_back(
+                    {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
+            for (uint32_t g0 = 0; g0 < ngroups; g0 += tile_groups) {
+                const uint64_t r_lo = s + (uint64_t)g0 * 32;
+                const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
+                for (uint64_t c0 = r_lo; c0 < e; c0 += BS_COL_CHUNK) {
+                    const uint64_t c1 = std::min<uint64_t>(e, c0 + BS_COL_CHUNK);
+                    const bool diag = c0 < r_hi;
+                    BsTask t{(uint32_t)s, (uint32_t)e, g0, ngroups, pl.plane_words,
+                             (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
+                    pl.bs_tasks[(wide ? 2 : 0) + (diag ? 0 : 1)].push_back(t);
+                    pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
+                }
+            }
+            pl.plane_words += (uint64_t)np * ngroups;
         } else {
             for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
                 for (uint64_t c0 = r0; c0 < e; c0 += BIG_COL_CHUNK) {
@@ -168,7 +204,8 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     const bool need_pairs =
         !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
     Plan pl;
-    build_plan(bucket_off, n_buckets, ctx->small_max, pl);
+    build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
+               pl);
     st.max_bucket = pl.max_bucket;
     st.n_pairs = pl.n_pairs;
     if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
@@ -180,8 +217,14 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
         (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
         return rc;
-    const size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size();
-    if ((rc = ctx->tasks.reserve(std::max<size_t>(1, n_tasks) * sizeof(PairTask)))) return rc;
+    const size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
+    if ((rc = ctx->tasks.reserve(
+             std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) * sizeof(PairTask))) ||
+        (rc = ctx->bs_tasks.reserve(std::max<size_t>(1, pl.n_bs()) * sizeof(BsTask))) ||
+        (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
+                                       sizeof(PlaneTask))) ||
+        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
+        return rc;
     if (mode == MODE_ADJACENCY && need_pairs)
         if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
 
@@ -192,6 +235,19 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     if (prof) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
     HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+    if (pl.n_bs()) {
+        BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
+        size_t off = 0;
+        for (auto &v : pl.bs_tasks) {
+            if (!v.empty())
+                HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
+                                       hipMemcpyHostToDevice, s));
+            off += v.size();
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
+                               pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice,
+                               s));
+    }
     if (n_tasks) {
         PairTask *d_tasks = ctx->tasks.as<PairTask>();
         if (!pl.small_tasks.empty())
@@ -206,6 +262,10 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
                         percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
                         ctx->label.as<uint32_t>(), d_cnt, s));
+    if (need_pairs && pl.n_bs())
+        HIP_TRY(launch_build_planes(ctx->fkey.p, key32, ctx->plane_tasks.as<PlaneTask>(),
+                                    (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
+                                    umi_len, s));
     if (prof) HIP_TRY(hipEventRecord(ev[1], s));
 
     uint64_t n_edges = 0;
@@ -230,10 +290,23 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             a.k = k;
             a.mode = mode;
             a.adj_max_freq = adj_max_freq;
+            a.planes = ctx->planes.as<uint32_t>();
+            a.bs_tasks = ctx->bs_tasks.as<BsTask>();
             a.tasks = ctx->tasks.as<PairTask>();
-            HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
+            // largest work first: wide bit-sliced tiles, narrow ones, then the popcount kernels
+            {
+                PairArgs b = a;
+                b.bs_tasks = a.bs_tasks + pl.bs_tasks[0].size() + pl.bs_tasks[1].size();
+                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[2].size(),
+                                        (uint32_t)pl.bs_tasks[3].size(), true, key32, umi_len, s));
+                HIP_TRY(launch_bs_pairs(a, (uint32_t)pl.bs_tasks[0].size(),
+                                        (uint32_t)pl.bs_tasks[1].size(), false, key32, umi_len, s));
+            }
             a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
             HIP_TRY(launch_pairs(a, (uint32_t)pl.big_tasks.size(), true, key32, s));
+            a.tasks = ctx->tasks.as<PairTask>();
+            HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
+            for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
             st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
             if (prof) HIP_TRY(hipEventRecord(ev[2], s));
             HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
@@ -390,7 +463,8 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
+    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes,
+                      &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
@@ -411,6 +485,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "bitslice")) {
+        ctx->use_bitslice = value != 0;
     } else if (!strcmp(name, "small_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "small_max must be >= 0");
         ctx->small_max = (uint32_t)std::min<int64_t>(value, 1 << 30);

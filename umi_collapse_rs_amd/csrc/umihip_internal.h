@@ -33,13 +33,37 @@ enum Counter : int {
     CNT_COUNT = 8,
 };
 
+// Bit-sliced kernel: one block works on rows [bucket_start + 32*group0, ...) of one
+// bucket (256*G or 64*G groups of 32 rows, see BS_* below) against columns [col0, col1).
+struct BsTask {
+    uint32_t bucket_start; // global index of the bucket's first entry
+    uint32_t bucket_end;
+    uint32_t group0;       // first 32-row group of this tile, relative to the bucket
+    uint32_t ngroups;      // groups in the bucket = ceil(n / 32)
+    uint64_t plane_off;    // word offset of the bucket's planes: planes[plane_off + b*ngroups + g]
+    uint32_t col0, col1;   // global column range
+    uint32_t diag;         // 1 if some column index <= some row index (needs the row<col mask)
+    uint32_t pad;
+};
+
+// One wave transposes 64 rows of one bucket into bit planes.
+struct PlaneTask {
+    uint32_t row0;       // global index of the first row
+    uint32_t bucket_end;
+    uint64_t plane_off;
+    uint32_t ngroups;
+    uint32_t group;      // group index of row0 inside the bucket (even)
+};
+
 struct PairArgs {
     const uint64_t *keys;
     const uint64_t *nmask; // may be null
     const int32_t *freq;
     const int32_t *thr;
-    const void *fkey; // uint32_t[N] (2 bits/base, umi_len <= 16) or uint64_t[N]
+    const void *fkey; // uint32_t[N] (2 bits/base, umi_len <= 16) or uint64_t[N] (see prep)
     const PairTask *tasks;
+    const BsTask *bs_tasks;
+    const uint32_t *planes;
     uint2 *edges;
     uint8_t *edge_dist; // MODE_NEIGHBOURS only
     unsigned long long *counters;
@@ -64,6 +88,21 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
                        unsigned long long *counters, hipStream_t s);
 
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);
+
+// bit-sliced path (buckets larger than small_max, k <= BS_MAX_K)
+constexpr int BS_MAX_K = 3;
+constexpr int BS_COL_TILE = 128;   // columns whose masks are staged in LDS per step
+constexpr int BS_COL_CHUNK = 4096; // columns per task
+constexpr int BS_WIDE_MIN = 32768; // buckets at least this large use 256-thread blocks
+// planes per key for a umi length: 2 bits per base, base count rounded up to 8/12/16/22
+inline int bs_padded_len(int umi_len) { return umi_len <= 8 ? 8 : umi_len <= 12 ? 12 : umi_len <= 16 ? 16 : 22; }
+inline int bs_groups_per_lane(int umi_len) { return umi_len <= 16 ? 2 : 1; }
+hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *tasks,
+                               uint32_t n_tasks, uint32_t *planes, int umi_len, hipStream_t s);
+// wide: 256-thread blocks (256*G groups per tile), else 64-thread blocks
+// (tasks ordered: n_diag diagonal tasks first, then n_off off-diagonal ones)
+hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide,
+                           bool key32, int umi_len, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a
 // no-op on the device when round r-1 changed nothing.

@@ -262,6 +262,156 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
         atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
 }
 
+// ---- bit-sliced all-pairs filter (large buckets) --------------------------------
+// Rows are held as bit planes of the 2-bit base code (plane 2i+j = bit j of base i; one
+// VGPR word = that bit of 32 consecutive rows), so one lane carries 32*G rows.  One
+// column at a time is applied as 2L wave-uniform masks (0 / ~0) read from an LDS tile:
+//     mismatch_i = (P[2i] ^ c[2i]) | (P[2i+1] ^ c[2i+1])          v_xor + v_bitop3
+// and a sticky counter saturating at K+1 runs over the bases in v_bitop3_b32 (any
+// 3-input boolean in one full-rate op on gfx950).  After the last base ~s[K+1] marks
+// the rows within distance K of the column: exact on the N-folded 2-bit code, hence
+// never above the reference distance; hits go through verify_pair like the other kernel.
+// K = 1 costs 3.5 full-rate VALU ops per base per 32 pairs (2 for the mask, 1.5 for the
+// counter with two bases folded per step) = 1.3 lane-ops per pair at L = 12.
+__device__ __forceinline__ uint32_t bit_of(uint32_t k, int b) { return (k >> b) & 1u; }
+__device__ __forceinline__ uint32_t bit_of(uint64_t k3, int b)
+{ // 64-bit filter keys keep the 3-bit layout: 2-bit code bit j of base i sits at 3i+j
+    const int pos = 3 * (b >> 1) + (b & 1);
+    return pos < 63 ? (uint32_t)(k3 >> pos) & 1u : 0u; // base 21 is padding (umi_len <= 21)
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict__ fkey,
+                                                          const PlaneTask *__restrict__ tasks,
+                                                          uint32_t *__restrict__ planes, int np)
+{
+    const PlaneTask t = tasks[blockIdx.x];
+    const uint32_t row = t.row0 + threadIdx.x;
+    const KeyT key = row < t.bucket_end ? fkey[row] : (KeyT)0;
+    for (int b = 0; b < np; b++) {
+        const unsigned long long bal = __ballot(bit_of(key, b));
+        if (threadIdx.x == 0) {
+            uint32_t *dst = planes + t.plane_off + (uint64_t)b * t.ngroups + t.group;
+            dst[0] = (uint32_t)bal;
+            if (t.group + 1 < t.ngroups) dst[1] = (uint32_t)(bal >> 32);
+        }
+    }
+}
+
+#define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
+
+template <typename KeyT, int LP, int G, int K, int THREADS, bool DIAG>
+__global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
+{
+    constexpr int NP = 2 * LP;
+    static_assert(LP % 2 == 0 && NP % 4 == 0, "padded base count must be even");
+    __shared__ __attribute__((aligned(16))) uint32_t cmask[BS_COL_TILE * NP];
+    __shared__ EdgeStage stage;
+    const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x;
+    const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(tp->bucket_start);
+    const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(tp->bucket_end);
+    const uint32_t group0 = __builtin_amdgcn_readfirstlane(tp->group0);
+    const uint32_t ngroups = __builtin_amdgcn_readfirstlane(tp->ngroups);
+    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0);
+    const uint32_t col1 = __builtin_amdgcn_readfirstlane(tp->col1);
+    const uint64_t plane_off = tp->plane_off;
+    const KeyT *__restrict__ fkey = (const KeyT *)a.fkey;
+    const uint32_t *__restrict__ planes = a.planes + plane_off;
+    const int tid = threadIdx.x;
+    const bool with_dist = a.mode == MODE_NEIGHBOURS;
+    const uint32_t n_rows = bucket_end - bucket_start;
+
+    if (tid == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+    }
+
+    uint32_t p[G][NP];
+    uint32_t valid[G];
+    uint32_t rbase[G]; // bucket-relative index of the group's first row
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const uint32_t grp = group0 + g * THREADS + tid;
+#pragma unroll
+        for (int b = 0; b < NP; b++) p[g][b] = grp < ngroups ? planes[(uint64_t)b * ngroups + grp] : 0u;
+        rbase[g] = grp * 32;
+        valid[g] = rbase[g] >= n_rows ? 0u
+                   : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
+    }
+
+    for (uint32_t c0 = col0; c0 < col1; c0 += BS_COL_TILE) {
+        const uint32_t nc = min((uint32_t)BS_COL_TILE, col1 - c0);
+        __syncthreads();
+        for (uint32_t w = tid; w < nc * NP; w += THREADS) {
+            const uint32_t c = w / NP, b = w % NP;
+            cmask[w] = bit_of(fkey[c0 + c], (int)b) ? 0xFFFFFFFFu : 0u;
+        }
+        __syncthreads();
+        for (uint32_t c = 0; c < nc; c++) {
+            uint32_t cm[NP];
+#pragma unroll
+            for (int q = 0; q < NP / 4; q++)
+                *reinterpret_cast<uint4 *>(&cm[4 * q]) =
+                    *reinterpret_cast<const uint4 *>(&cmask[c * NP + 4 * q]);
+            uint32_t h[G];
+            uint32_t anyhit = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                uint32_t s[K + 2]; // s[l] = rows with at least l mismatches so far (l = 1..K+1)
+#pragma unroll
+                for (int l = 0; l < K + 2; l++) s[l] = 0;
+#pragma unroll
+                for (int i = 0; i < LP; i += 2) {
+                    const uint32_t ta = p[g][2 * i] ^ cm[2 * i];
+                    const uint32_t ma = BITOP3(ta, p[g][2 * i + 1], cm[2 * i + 1], TT_A | (TT_B ^ TT_C));
+                    const uint32_t tb = p[g][2 * i + 2] ^ cm[2 * i + 2];
+                    const uint32_t mb = BITOP3(tb, p[g][2 * i + 3], cm[2 * i + 3], TT_A | (TT_B ^ TT_C));
+                    if (K == 0) {
+                        s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
+                    } else if (K == 1) {
+                        // two bases per step: >=2 of {s1, ma, mb} feeds s2
+                        s[2] |= BITOP3(s[1], ma, mb, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                        s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
+                    } else {
+#pragma unroll
+                        for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
+                        s[1] |= ma;
+#pragma unroll
+                        for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], mb, TT_A | (TT_B & TT_C));
+                        s[1] |= mb;
+                    }
+                }
+                uint32_t hg = ~s[K + 1] & valid[g];
+                if (DIAG) { // only rows before the column: keeps the self pair and i > j out
+                    const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
+                    const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
+                    hg &= lt;
+                }
+                h[g] = hg;
+                anyhit |= hg;
+            }
+            if (__any(anyhit != 0)) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    uint32_t hh = h[g];
+                    while (hh) {
+                        const int j = __builtin_ctz(hh);
+                        hh &= hh - 1;
+                        verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
+                                    &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
+                                    bucket_start + rbase[g] + j, c0 + c);
+                    }
+                }
+            }
+        }
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist);
+    }
+    __syncthreads();
+    if (tid == 0 && stage.candidates)
+        atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
+}
+
 // ---- collapse: directed min-rank label propagation ---------------------------
 __global__ __launch_bounds__(256) void hook_kernel(const uint2 *__restrict__ edges,
                                                    const unsigned long long *counters,
@@ -409,6 +559,61 @@ hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key3
             pair_kernel<uint32_t, SMALL_THREADS, SMALL_RPT><<<n_tasks, SMALL_THREADS, 0, s>>>(a);
         else
             pair_kernel<uint64_t, SMALL_THREADS, SMALL_RPT><<<n_tasks, SMALL_THREADS, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *tasks,
+                               uint32_t n_tasks, uint32_t *planes, int umi_len, hipStream_t s)
+{
+    if (n_tasks == 0) return hipSuccess;
+    const int np = 2 * bs_padded_len(umi_len);
+    if (key32)
+        build_planes_kernel<uint32_t><<<n_tasks, 64, 0, s>>>((const uint32_t *)fkey2, tasks, planes, np);
+    else
+        build_planes_kernel<uint64_t><<<n_tasks, 64, 0, s>>>((const uint64_t *)fkey2, tasks, planes, np);
+    return hipGetLastError();
+}
+
+namespace {
+template <typename KeyT, int LP, int G, int K>
+void launch_bs_k(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide, hipStream_t s)
+{
+    // tasks are ordered diagonal first
+    PairArgs b = a;
+    if (wide) {
+        if (n_diag) bs_pair_kernel<KeyT, LP, G, K, 256, true><<<n_diag, 256, 0, s>>>(a);
+        b.bs_tasks = a.bs_tasks + n_diag;
+        if (n_off) bs_pair_kernel<KeyT, LP, G, K, 256, false><<<n_off, 256, 0, s>>>(b);
+    } else {
+        if (n_diag) bs_pair_kernel<KeyT, LP, G, K, 64, true><<<n_diag, 64, 0, s>>>(a);
+        b.bs_tasks = a.bs_tasks + n_diag;
+        if (n_off) bs_pair_kernel<KeyT, LP, G, K, 64, false><<<n_off, 64, 0, s>>>(b);
+    }
+}
+template <typename KeyT, int LP, int G>
+void launch_bs_lp(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide, hipStream_t s)
+{
+    switch (a.k) {
+    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_diag, n_off, wide, s); break;
+    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_diag, n_off, wide, s); break;
+    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_diag, n_off, wide, s); break;
+    default: launch_bs_k<KeyT, LP, G, 3>(a, n_diag, n_off, wide, s); break;
+    }
+}
+} // namespace
+
+hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide,
+                           bool key32, int umi_len, hipStream_t s)
+{
+    if (n_diag + n_off == 0) return hipSuccess;
+    const int lp = bs_padded_len(umi_len);
+    if (key32) {
+        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_diag, n_off, wide, s);
+        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_diag, n_off, wide, s);
+        else launch_bs_lp<uint32_t, 16, 2>(a, n_diag, n_off, wide, s);
+    } else {
+        launch_bs_lp<uint64_t, 22, 1>(a, n_diag, n_off, wide, s);
     }
     return hipGetLastError();
 }
