@@ -26,7 +26,13 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-OPS_PER_PAIR = 2.5   # v_xor + v_bcnt + half a v_min3 (kernel K1)
+# Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter, k = 1): per
+# column and 32-row group, 12 bases x (2 mask ops + 1.5 sticky-counter ops) = 42 full-rate
+# 32-bit ops for 32 pairs (kernel K1b)
+def ops_per_pair(umi_len, k):
+    lp = 8 if umi_len <= 8 else 12 if umi_len <= 12 else 16 if umi_len <= 16 else 22
+    per_base = 2.0 + (0.5 if k == 0 else 1.5 if k == 1 else k + 1.0)
+    return lp * per_base / 32.0
 BYTES_PER_UMI = 16   # 8 B key + 4 B freq in, 4 B label out
 
 
@@ -143,7 +149,8 @@ def main():
         pair_ms = float(np.mean([s["ms_pairs"] for s in stats]))
         coll_ms = float(np.mean([s["ms_collapse"] for s in stats]))
         s0 = stats[-1]
-        achieved = OPS_PER_PAIR * w_local / (pair_ms * 1e-3) / 1e12
+        opp = ops_per_pair(args.umi_len, args.k)
+        achieved = opp * w_local / (pair_ms * 1e-3) / 1e12
         out = {
             "metric": "UMI-pair Hamming comparisons/s (12-bp UMIs, all-pairs adjacency + "
                       "directional collapse)",
@@ -161,13 +168,15 @@ def main():
             "reads_per_s": reads_total * args.steps / dt,
             "kept_rank0": kept_n,
             "roofline": {
-                "bound": "valu", "kernel": "pair_kernel<u32,256,8>",
+                "bound": "valu", "kernel": "bs_pair_kernel (bit-sliced all-pairs filter)",
                 "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
                 "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": None,
-                "ops_per_pair": OPS_PER_PAIR, "pairs_per_launch": w_local,
+                "ops_per_pair": opp, "pairs_per_launch": w_local,
                 "kernel_ms": pair_ms,
-                "note": "integer VALU-bound (0 algorithmic HBM bytes per pair, LDS-reused "
-                        "column tiles); no MFMA.  HBM view in roofline_hbm."},
+                "note": "integer VALU-bound (0 algorithmic HBM bytes per pair, LDS-staged "
+                        "column masks); no MFMA.  achieved = ops_per_pair x W / time of the pair "
+                        "kernels of one step (HIP events); peak = 256 CU x 4 SIMD x 32 lanes x "
+                        "2.4 GHz.  HBM view in roofline_hbm."},
             "roofline_hbm": {
                 "bound": "hbm", "achieved": BYTES_PER_UMI * n / (ms_step * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
