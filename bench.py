@@ -67,6 +67,7 @@ def main():
     ap.add_argument("-p", type=float, default=0.5)
     ap.add_argument("--cpu-sample", type=int, default=80_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="ctx option name=value (tuning)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,9 @@ def main():
     gather_out = torch.zeros(max_n * world, dtype=torch.uint8, device=dev) if world > 1 else None
 
     ctx = umi.Context(local_rank, profile=True)
+    for o in args.opt:
+        name, val = o.split("=")
+        ctx.set_option(name, int(val))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

@@ -72,7 +72,8 @@ const char *umi_last_error(void);
 /* Options: "profile" (0/1: record HIP events, fill ms_*), "edge_capacity"
  * (initial edge-list capacity, entries), "small_max" (largest bucket handled by
  * the wave-per-chunk kernel), "bitslice" (0/1: use the bit-sliced tile kernel for
- * larger buckets, default 1; 0 = popcount tile kernel).  Unknown name -> UMI_ERR_ARG. */
+ * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
+ * bit-sliced task).  Unknown name -> UMI_ERR_ARG. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
 /* 1 if this library was built with device code for gfx950 (always), for loaders */
 int umi_abi_version(void);

@@ -73,14 +73,14 @@ struct DevBuf {
 
 struct Plan {
     std::vector<PairTask> small_tasks, big_tasks;
-    // bit-sliced tasks: [0] narrow diagonal, [1] narrow off-diagonal, [2] wide diag, [3] wide off
-    std::vector<BsTask> bs_tasks[4];
+    // bit-sliced tasks: [0] 64-thread tiles, [1] 256-thread tiles (diagonal tiles first)
+    std::vector<BsTask> bs_tasks[2];
     std::vector<PlaneTask> plane_tasks;
     uint64_t plane_words = 0;
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
     size_t n_bs() const
     {
-        return bs_tasks[0].size() + bs_tasks[1].size() + bs_tasks[2].size() + bs_tasks[3].size();
+        return bs_tasks[0].size() + bs_tasks[1].size();
     }
 };
 
@@ -97,6 +97,7 @@ struct umi_ctx {
     uint64_t edge_capacity = 1u << 20;
     uint32_t small_max = 1024;
     bool use_bitslice = true;
+    uint32_t bs_col_chunk = BS_COL_CHUNK;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
@@ -110,7 +111,7 @@ struct umi_ctx {
 namespace {
 
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, Plan &pl)
+                int umi_len, uint32_t col_chunk, Plan &pl)
 {
     pl.small_tasks.clear();
     pl.big_tasks.clear();
@@ -141,12 +142,12 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             for (uint32_t g0 = 0; g0 < ngroups; g0 += tile_groups) {
                 const uint64_t r_lo = s + (uint64_t)g0 * 32;
                 const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
-                for (uint64_t c0 = r_lo; c0 < e; c0 += BS_COL_CHUNK) {
-                    const uint64_t c1 = std::min<uint64_t>(e, c0 + BS_COL_CHUNK);
+                for (uint64_t c0 = r_lo; c0 < e; c0 += col_chunk) {
+                    const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
                     const bool diag = c0 < r_hi;
                     BsTask t{(uint32_t)s, (uint32_t)e, g0, ngroups, pl.plane_words,
                              (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
-                    pl.bs_tasks[(wide ? 2 : 0) + (diag ? 0 : 1)].push_back(t);
+                    pl.bs_tasks[wide ? 1 : 0].push_back(t);
                     pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
                 }
             }
@@ -205,7 +206,7 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
     Plan pl;
     build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
-               pl);
+               ctx->bs_col_chunk, pl);
     st.max_bucket = pl.max_bucket;
     st.n_pairs = pl.n_pairs;
     if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
@@ -296,11 +297,11 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             // largest work first: wide bit-sliced tiles, narrow ones, then the popcount kernels
             {
                 PairArgs b = a;
-                b.bs_tasks = a.bs_tasks + pl.bs_tasks[0].size() + pl.bs_tasks[1].size();
-                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[2].size(),
-                                        (uint32_t)pl.bs_tasks[3].size(), true, key32, umi_len, s));
-                HIP_TRY(launch_bs_pairs(a, (uint32_t)pl.bs_tasks[0].size(),
-                                        (uint32_t)pl.bs_tasks[1].size(), false, key32, umi_len, s));
+                b.bs_tasks = a.bs_tasks + pl.bs_tasks[0].size();
+                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
+                                        s));
+                HIP_TRY(launch_bs_pairs(a, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
+                                        s));
             }
             a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
             HIP_TRY(launch_pairs(a, (uint32_t)pl.big_tasks.size(), true, key32, s));
@@ -485,6 +486,10 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "bs_col_chunk")) {
+        if (value < BS_COL_TILE || value > (1 << 24))
+            return fail(UMI_ERR_ARG, "bs_col_chunk outside %d..%d", BS_COL_TILE, 1 << 24);
+        ctx->bs_col_chunk = (uint32_t)value;
     } else if (!strcmp(name, "bitslice")) {
         ctx->use_bitslice = value != 0;
     } else if (!strcmp(name, "small_max")) {

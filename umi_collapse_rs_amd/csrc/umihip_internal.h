@@ -92,7 +92,7 @@ hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key3
 // bit-sliced path (buckets larger than small_max, k <= BS_MAX_K)
 constexpr int BS_MAX_K = 3;
 constexpr int BS_COL_TILE = 128;   // columns whose masks are staged in LDS per step
-constexpr int BS_COL_CHUNK = 4096; // columns per task
+constexpr int BS_COL_CHUNK = 2048; // default columns per task (ctx option bs_col_chunk)
 constexpr int BS_WIDE_MIN = 32768; // buckets at least this large use 256-thread blocks
 // planes per key for a umi length: 2 bits per base, base count rounded up to 8/12/16/22
 inline int bs_padded_len(int umi_len) { return umi_len <= 8 ? 8 : umi_len <= 12 ? 12 : umi_len <= 16 ? 16 : 22; }
@@ -100,9 +100,8 @@ inline int bs_groups_per_lane(int umi_len) { return umi_len <= 16 ? 2 : 1; }
 hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *tasks,
                                uint32_t n_tasks, uint32_t *planes, int umi_len, hipStream_t s);
 // wide: 256-thread blocks (256*G groups per tile), else 64-thread blocks
-// (tasks ordered: n_diag diagonal tasks first, then n_off off-diagonal ones)
-hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide,
-                           bool key32, int umi_len, hipStream_t s);
+hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
+                           int umi_len, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a
 // no-op on the device when round r-1 changed nothing.

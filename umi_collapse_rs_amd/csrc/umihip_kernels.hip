@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict
 #define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
 constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
 
-template <typename KeyT, int LP, int G, int K, int THREADS, bool DIAG>
+template <typename KeyT, int LP, int G, int K, int THREADS>
 __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
 {
     constexpr int NP = 2 * LP;
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
     const uint32_t ngroups = __builtin_amdgcn_readfirstlane(tp->ngroups);
     const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0);
     const uint32_t col1 = __builtin_amdgcn_readfirstlane(tp->col1);
+    const bool diag = __builtin_amdgcn_readfirstlane(tp->diag) != 0; // wave-uniform
     const uint64_t plane_off = tp->plane_off;
     const KeyT *__restrict__ fkey = (const KeyT *)a.fkey;
     const uint32_t *__restrict__ planes = a.planes + plane_off;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
                     }
                 }
                 uint32_t hg = ~s[K + 1] & valid[g];
-                if (DIAG) { // only rows before the column: keeps the self pair and i > j out
+                if (diag) { // only rows before the column: keeps the self pair and i > j out
                     const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
                     const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
                     hg &= lt;
@@ -452,6 +453,19 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
     if (any) changed[round] = 1;
 }
 
+// sum `cnt` over the block (256 threads) and add it to *dst with one atomic
+__device__ __forceinline__ void block_count_add(unsigned int cnt, unsigned long long *dst)
+{
+    __shared__ unsigned int part[4];
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(dst, (unsigned long long)t);
+    }
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ label,
                                                        uint32_t n, uint8_t *__restrict__ kept,
                                                        uint32_t *__restrict__ root,
@@ -465,9 +479,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restric
         if (root) root[i] = l;
         cnt += kp ? 1u : 0u;
     }
-    // wave reduction, one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[CNT_KEPT], (unsigned long long)cnt);
+    block_count_add(cnt, &counters[CNT_KEPT]);
 }
 
 // ---- adjacency with max_freq > 0: greedy independent set in rank order --------
@@ -503,8 +515,7 @@ __global__ __launch_bounds__(256) void adj_promote_kernel(uint8_t *status, uint8
         }
         blocked[v] = 0;
     }
-    for (int off = 32; off > 0; off >>= 1) unk += __shfl_down(unk, off);
-    if ((threadIdx.x & 63) == 0 && unk) atomicAdd(&counters[CNT_UNKNOWN], (unsigned long long)unk);
+    block_count_add(unk, &counters[CNT_UNKNOWN]);
 }
 
 __global__ __launch_bounds__(256) void adj_finalize_kernel(const uint8_t *__restrict__ status,
@@ -520,8 +531,7 @@ __global__ __launch_bounds__(256) void adj_finalize_kernel(const uint8_t *__rest
         if (root) root[i] = kp ? i : label[i];
         cnt += kp ? 1u : 0u;
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[CNT_KEPT], (unsigned long long)cnt);
+    block_count_add(cnt, &counters[CNT_KEPT]);
 }
 
 inline uint32_t grid_for(uint64_t work, int block, uint32_t cap = 2048)
@@ -577,43 +587,36 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 
 namespace {
 template <typename KeyT, int LP, int G, int K>
-void launch_bs_k(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide, hipStream_t s)
+void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, hipStream_t s)
 {
-    // tasks are ordered diagonal first
-    PairArgs b = a;
-    if (wide) {
-        if (n_diag) bs_pair_kernel<KeyT, LP, G, K, 256, true><<<n_diag, 256, 0, s>>>(a);
-        b.bs_tasks = a.bs_tasks + n_diag;
-        if (n_off) bs_pair_kernel<KeyT, LP, G, K, 256, false><<<n_off, 256, 0, s>>>(b);
-    } else {
-        if (n_diag) bs_pair_kernel<KeyT, LP, G, K, 64, true><<<n_diag, 64, 0, s>>>(a);
-        b.bs_tasks = a.bs_tasks + n_diag;
-        if (n_off) bs_pair_kernel<KeyT, LP, G, K, 64, false><<<n_off, 64, 0, s>>>(b);
-    }
+    if (wide)
+        bs_pair_kernel<KeyT, LP, G, K, 256><<<n_tasks, 256, 0, s>>>(a);
+    else
+        bs_pair_kernel<KeyT, LP, G, K, 64><<<n_tasks, 64, 0, s>>>(a);
 }
 template <typename KeyT, int LP, int G>
-void launch_bs_lp(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide, hipStream_t s)
+void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_diag, n_off, wide, s); break;
-    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_diag, n_off, wide, s); break;
-    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_diag, n_off, wide, s); break;
-    default: launch_bs_k<KeyT, LP, G, 3>(a, n_diag, n_off, wide, s); break;
+    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_tasks, wide, s); break;
+    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_tasks, wide, s); break;
+    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_tasks, wide, s); break;
+    default: launch_bs_k<KeyT, LP, G, 3>(a, n_tasks, wide, s); break;
     }
 }
 } // namespace
 
-hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_diag, uint32_t n_off, bool wide,
-                           bool key32, int umi_len, hipStream_t s)
+hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
+                           int umi_len, hipStream_t s)
 {
-    if (n_diag + n_off == 0) return hipSuccess;
+    if (n_tasks == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
     if (key32) {
-        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_diag, n_off, wide, s);
-        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_diag, n_off, wide, s);
-        else launch_bs_lp<uint32_t, 16, 2>(a, n_diag, n_off, wide, s);
+        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_tasks, wide, s);
+        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_tasks, wide, s);
+        else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, s);
     } else {
-        launch_bs_lp<uint64_t, 22, 1>(a, n_diag, n_off, wide, s);
+        launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, s);
     }
     return hipGetLastError();
 }
@@ -632,7 +635,7 @@ hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uin
                            unsigned long long *counters, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    finalize_kernel<<<grid_for(n, 256), 256, 0, s>>>(label, n, kept, root, counters);
+    finalize_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(label, n, kept, root, counters);
     return hipGetLastError();
 }
 
@@ -643,7 +646,7 @@ hipError_t launch_adj_iter(const uint2 *edges, const unsigned long long *counter
 {
     adj_mark_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, status,
                                                                 blocked, label);
-    adj_promote_kernel<<<grid_for(n, 256), 256, 0, s>>>(status, blocked, n, counters_rw);
+    adj_promote_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(status, blocked, n, counters_rw);
     return hipGetLastError();
 }
 
@@ -652,7 +655,7 @@ hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, uin
                                hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    adj_finalize_kernel<<<grid_for(n, 256), 256, 0, s>>>(status, label, n, kept, root, counters);
+    adj_finalize_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(status, label, n, kept, root, counters);
     return hipGetLastError();
 }
 
