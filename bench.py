@@ -148,6 +148,18 @@ def main():
     kept_n = int(d_kept.sum().item())
     assert kept_n == stats[-1]["n_kept"]
 
+    # the same pass through the host-buffer entry point (H2D of keys/freq + D2H of the mask
+    # inside the call): the PCIe-inclusive rate, reported beside `value`, never as it
+    host_ms = None
+    if rank == 0 and world == 1:
+        ctx.dedup_batch(st["keys"], None, st["freq"], boff, args.umi_len, k=args.k,
+                        percentage=args.p, want_root=False)
+        t1 = time.perf_counter()
+        hk, _, _ = ctx.dedup_batch(st["keys"], None, st["freq"], boff, args.umi_len, k=args.k,
+                                   percentage=args.p, want_root=False)
+        host_ms = (time.perf_counter() - t1) * 1e3
+        assert int(hk.sum()) == kept_n
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         pair_ms = float(np.mean([s["ms_pairs"] for s in stats]))
@@ -170,6 +182,9 @@ def main():
                        "unique_umis_rank0": n, "pairs_W_total": w_total,
                        "parallelism": "bucket-sharded x%d" % world},
             "reads_per_s": reads_total * args.steps / dt,
+            "host_buffer_path": None if host_ms is None else {
+                "ms_per_call": host_ms, "pairs_per_s": w_local / (host_ms * 1e-3),
+                "note": "umi_dedup_batch with pageable host arrays: PCIe copies included"},
             "kept_rank0": kept_n,
             "roofline": {
                 "bound": "valu", "kernel": "bs_pair_kernel (bit-sliced all-pairs filter)",
