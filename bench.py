@@ -36,24 +36,33 @@ def ops_per_pair(umi_len, k):
 BYTES_PER_UMI = 16   # 8 B key + 4 B freq in, 4 B label out
 
 
-def cpu_baseline(st, n_sample, k, p):
-    """The oracle (a scalar C port of the reference path) on a bounded sample of the
-    same bucket: n_sample unique UMIs drawn in rank order from the staged position."""
+def cpu_baseline(st, n_sample, k, p, umi_len=12, config=2):
+    """The oracle (a scalar C port of the reference path) on a bounded sample of the same
+    workload: config 2 -> n_sample unique UMIs drawn in rank order from the staged position;
+    configs 3/5 -> a prefix of whole buckets."""
     import oracle as orc
     n = len(st["keys"])
-    rng = np.random.default_rng(12345)
-    idx = np.sort(rng.choice(n, size=min(n_sample, n), replace=False))
-    keys, freq = st["keys"][idx], st["freq"][idx]
-    m = len(idx)
+    if config == 2:
+        rng = np.random.default_rng(12345)
+        idx = np.sort(rng.choice(n, size=min(n_sample, n), replace=False))
+        keys, freq = st["keys"][idx], st["freq"][idx]
+        boff = np.array([0, len(idx)], np.uint64)
+        what = "%d unique UMIs sampled in rank order from the same position" % len(idx)
+    else:
+        nb = min(len(st["bucket_off"]) - 1, 50_000)
+        boff = st["bucket_off"][: nb + 1]
+        m = int(boff[-1])
+        keys, freq = st["keys"][:m], st["freq"][:m]
+        what = "the first %d buckets (%d unique UMIs)" % (nb, m)
+    sz = np.diff(boff.astype(np.int64))
+    w = int((sz * (sz - 1) // 2).sum())
     t0 = time.perf_counter()
-    kept, _, calls = orc.dedup_batch(keys, None, freq, np.array([0, m], np.uint64), 12, k, p)
+    kept, _, calls = orc.dedup_batch(keys, None, freq, boff, umi_len, k, p)
     dt = time.perf_counter() - t0
-    w = m * (m - 1) // 2
     return {"value": w / dt, "unit": "UMI-pair comparisons/s", "cores": 1, "kind": "port",
-            "sample": "%d unique UMIs sampled in rank order from the same position "
-                      "(W=%d pairs, %d umi_dist calls, %.1f s); the Rust reference cannot be "
-                      "built here (no rustc)" % (m, w, calls, dt),
-            "dist_calls_per_s": calls / dt}
+            "sample": "%s (W=%d pairs, %d umi_dist calls, %.1f s); the Rust reference cannot be "
+                      "built here (no rustc)" % (what, w, calls, dt),
+            "dist_calls_per_s": calls / dt, "umis_per_s": len(keys) / dt}
 
 
 def main():
@@ -68,6 +77,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=80_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="ctx option name=value (tuning)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE config per GPU: 2 = one giant position (headline), 3 = 10M reads "
+                         "in 100k positions, 5 = 20-bp UMIs k=2 in many positions (parity-test "
+                         "shapes; the judged bench line is config 2)")
     args = ap.parse_args()
 
     import torch
@@ -90,9 +103,26 @@ def main():
     from umi_collapse_rs_amd.sharded import partition_buckets
 
     # ---- workload: position `rank` of the N-position job (config 2 per GPU)
-    st = synth.config2(seed=2 + 1000 * rank, n_reads=args.reads, umi_len=args.umi_len)
+    if args.config == 2:
+        st = synth.config2(seed=2 + 1000 * rank, n_reads=args.reads, umi_len=args.umi_len)
+        workload = ("BASELINE config 2 per GPU: %d reads, %d-bp UMIs, one alignment position "
+                    "(uniform UMIs)" % (args.reads, args.umi_len))
+    elif args.config == 3:
+        args.reads = 10_000_000 if args.reads == 1_000_000 else args.reads
+        st = synth.config3(seed=3 + 1000 * rank, n_reads=args.reads,
+                           n_positions=args.reads // 100, umi_len=args.umi_len)
+        workload = ("BASELINE config 3 per GPU: %d reads, %d-bp UMIs, %d alignment positions "
+                    "(molecule model)" % (args.reads, args.umi_len, args.reads // 100))
+    else:
+        args.umi_len, args.k = 20, 2
+        args.reads = 6_250_000 if args.reads == 1_000_000 else args.reads
+        st = synth.config3(seed=5 + 1000 * rank, n_reads=args.reads,
+                           n_positions=args.reads // 100, umi_len=20)
+        workload = ("BASELINE config 5 per GPU: %d reads, 20-bp UMIs, %d alignment positions, "
+                    "k=2 (molecule model)" % (args.reads, args.reads // 100))
     n = len(st["keys"])
-    w_local = n * (n - 1) // 2
+    nb_sizes = np.diff(st["bucket_off"].astype(np.int64))
+    w_local = int((nb_sizes * (nb_sizes - 1) // 2).sum())
     sizes = [n]
     if world > 1:
         t = torch.tensor([n], dtype=torch.int64, device=dev)
@@ -101,7 +131,7 @@ def main():
         sizes = [int(x.item()) for x in allt]
         parts = partition_buckets(sizes, world)
         assert sorted(int(p[0]) for p in parts) == list(range(world))
-    w_total = sum(s * (s - 1) // 2 for s in sizes)
+    w_total = w_local * world if args.config != 2 else sum(s * (s - 1) // 2 for s in sizes)
     reads_total = args.reads * world
 
     d_keys = torch.from_numpy(st["keys"].view(np.int64)).to(dev)
@@ -175,9 +205,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2 per GPU: %d reads, %d-bp UMIs, one "
-                                   "alignment position (uniform UMIs), --data naive --algo dir "
-                                   "-k %d -p %g" % (args.reads, args.umi_len, args.k, args.p),
+            "config": {"workload": "%s, --data naive --algo dir -k %d -p %g" % (
+                           workload, args.k, args.p),
                        "reads_per_position": args.reads, "positions": world,
                        "unique_umis_rank0": n, "pairs_W_total": w_total,
                        "parallelism": "bucket-sharded x%d" % world},
@@ -208,7 +237,8 @@ def main():
                          "n_rounds": s0["n_rounds"], "pairs_evaluated": s0["n_pairs_evaluated"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(st, args.cpu_sample, args.k, args.p)
+            out["cpu_baseline"] = cpu_baseline(st, args.cpu_sample, args.k, args.p, args.umi_len,
+                                               args.config)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -73,7 +73,8 @@ const char *umi_last_error(void);
  * (initial edge-list capacity, entries), "small_max" (largest bucket handled by
  * the wave-per-chunk kernel), "bitslice" (0/1: use the bit-sliced tile kernel for
  * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
- * bit-sliced task).  Unknown name -> UMI_ERR_ARG. */
+ * bit-sliced task), "fused_max" (largest bucket handled by the fused one-wave-per-bucket
+ * kernel, 0..128, default 128).  Unknown name -> UMI_ERR_ARG. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
 /* 1 if this library was built with device code for gfx950 (always), for loaders */
 int umi_abi_version(void);

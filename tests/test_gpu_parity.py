@@ -8,10 +8,14 @@ from helpers import canonical, random_bucket
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["default", "nofuse"])
+def ctx(request):
+    """default: fused one-wave kernel for buckets <= 128, popcount chunks to 1024, bit-sliced
+    tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
+    if request.param == "nofuse":
+        c.set_option("fused_max", 0)
     yield c
     c.close()
 
@@ -79,6 +83,28 @@ def test_random_buckets_adjacency(ctx, amf):
     keys, nm, fr, off = make_batch(rng, 50, 10, 40, err=0.08)
     check_against_oracle(ctx, keys, nm, fr, off, 10, 1, algo=1, amf=amf)
     check_against_oracle(ctx, keys, nm, fr, off, 10, 2, algo=1, amf=amf)
+
+
+def test_bucket_sizes_around_kernel_boundaries(ctx):
+    """Buckets of exactly 1, 2, 63, 64, 65, 127, 128, 129 entries (fused 1- and 2-row
+    variants, then the chunk kernel), with N and with p > 0.5."""
+    rng = np.random.default_rng(77)
+    for L, k, p, n_frac in ((9, 1, 0.5, 0.0), (12, 2, 1.0, 0.02), (20, 1, 0.5, 0.01)):
+        keys, nm, fr, off = [], [], [], [0]
+        for n in (1, 2, 63, 64, 65, 127, 128, 129, 64, 128):
+            umis, freq = [], []
+            while len(umis) < n:
+                u, f = random_bucket(rng, 40, L, err=0.15, n_frac=n_frac)
+                for a, b in zip(u, f):
+                    if a not in umis and len(umis) < n:
+                        umis.append(a); freq.append(b)
+            umis, freq, _ = canonical(umis, freq)
+            kk, mm = orc.encode_keys(umis)
+            keys.append(kk); nm.append(mm); fr.extend(freq); off.append(off[-1] + n)
+        check_against_oracle(ctx, np.concatenate(keys), np.concatenate(nm), np.array(fr, np.int32),
+                             np.array(off, np.uint64), L, k, p)
+        check_against_oracle(ctx, np.concatenate(keys), np.concatenate(nm), np.array(fr, np.int32),
+                             np.array(off, np.uint64), L, k, algo=1, amf=2)
 
 
 def test_empty_and_degenerate_inputs(ctx):

@@ -76,6 +76,7 @@ struct Plan {
     // bit-sliced tasks: [0] 64-thread tiles, [1] 256-thread tiles (diagonal tiles first)
     std::vector<BsTask> bs_tasks[2];
     std::vector<PlaneTask> plane_tasks;
+    std::vector<SmallTask> fused_tasks[2]; // [0] n <= 64 (1 row per lane), [1] n <= 128
     uint64_t plane_words = 0;
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
     size_t n_bs() const
@@ -98,9 +99,10 @@ struct umi_ctx {
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
+    uint32_t fused_max = FUSED_MAX;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
-    DevBuf bs_tasks, plane_tasks, planes;
+    DevBuf bs_tasks, plane_tasks, planes, fused_tasks;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
     unsigned long long *h_counters = nullptr; // pinned
@@ -111,8 +113,9 @@ struct umi_ctx {
 namespace {
 
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, uint32_t col_chunk, Plan &pl)
+                int umi_len, uint32_t col_chunk, uint32_t fused_max, Plan &pl)
 {
+    for (auto &v : pl.fused_tasks) v.clear();
     pl.small_tasks.clear();
     pl.big_tasks.clear();
     for (auto &v : pl.bs_tasks) v.clear();
@@ -127,7 +130,10 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
         pl.max_bucket = std::max(pl.max_bucket, n);
         if (n < 2) continue;
         pl.n_pairs += n * (n - 1) / 2;
-        if (n <= small_max) {
+        if (n <= fused_max) {
+            pl.fused_tasks[n <= 64 ? 0 : 1].push_back({(uint32_t)s, (uint32_t)n});
+            pl.n_pairs_eval += n * n;
+        } else if (n <= small_max) {
             for (uint64_t r0 = s; r0 < e; r0 += SMALL_ROWS) {
                 pl.small_tasks.push_back({(uint32_t)r0, (uint32_t)e, (uint32_t)r0, (uint32_t)e});
                 pl.n_pairs_eval += (uint64_t)SMALL_ROWS * (((e - r0) + 31) / 32 * 32);
@@ -206,7 +212,9 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
     Plan pl;
     build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
-               ctx->bs_col_chunk, pl);
+               ctx->bs_col_chunk,
+               (mode == MODE_NEIGHBOURS || !need_pairs) ? 0u : std::min<uint32_t>(ctx->fused_max, FUSED_MAX),
+               pl);
     st.max_bucket = pl.max_bucket;
     st.n_pairs = pl.n_pairs;
     if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
@@ -224,10 +232,14 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         (rc = ctx->bs_tasks.reserve(std::max<size_t>(1, pl.n_bs()) * sizeof(BsTask))) ||
         (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
                                        sizeof(PlaneTask))) ||
-        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
+        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))) ||
+        (rc = ctx->fused_tasks.reserve(
+             std::max<size_t>(1, pl.fused_tasks[0].size() + pl.fused_tasks[1].size()) *
+             sizeof(SmallTask))))
         return rc;
     if (mode == MODE_ADJACENCY && need_pairs)
         if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
+    const size_t n_fused = pl.fused_tasks[0].size() + pl.fused_tasks[1].size();
 
     unsigned long long *d_cnt = ctx->counters.as<unsigned long long>();
     hipEvent_t *ev = ctx->ev;
@@ -236,6 +248,21 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     if (prof) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
     HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_fused) {
+        SmallTask *d_f = ctx->fused_tasks.as<SmallTask>();
+        if (!pl.fused_tasks[0].empty())
+            HIP_TRY(hipMemcpyAsync(d_f, pl.fused_tasks[0].data(),
+                                   pl.fused_tasks[0].size() * sizeof(SmallTask),
+                                   hipMemcpyHostToDevice, s));
+        if (!pl.fused_tasks[1].empty())
+            HIP_TRY(hipMemcpyAsync(d_f + pl.fused_tasks[0].size(), pl.fused_tasks[1].data(),
+                                   pl.fused_tasks[1].size() * sizeof(SmallTask),
+                                   hipMemcpyHostToDevice, s));
+    }
+    if (mode == MODE_ADJACENCY && need_pairs) {
+        HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
+        HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
+    }
     if (pl.n_bs()) {
         BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
         size_t off = 0;
@@ -269,6 +296,20 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                                     umi_len, s));
     if (prof) HIP_TRY(hipEventRecord(ev[1], s));
 
+    // whole small buckets, all-pairs and collapse fused, straight to label[] / status[]
+    if (n_fused) {
+        const SmallTask *d_f = ctx->fused_tasks.as<SmallTask>();
+        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(), d_f,
+                                     (uint32_t)pl.fused_tasks[0].size(), 1,
+                                     ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
+                                     adj_max_freq, s));
+        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
+                                     d_f + pl.fused_tasks[0].size(),
+                                     (uint32_t)pl.fused_tasks[1].size(), 2,
+                                     ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
+                                     adj_max_freq, s));
+        st.n_pair_launches += (pl.fused_tasks[0].empty() ? 0 : 1) + (pl.fused_tasks[1].empty() ? 0 : 1);
+    }
     uint64_t n_edges = 0;
     uint32_t cap_used = 0;
     if (need_pairs && n_tasks) {
@@ -378,8 +419,6 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         // adjacency with max_freq >= 1
         uint8_t *d_status = ctx->status.as<uint8_t>();
         uint8_t *d_blocked = ctx->blocked.as<uint8_t>();
-        HIP_TRY(hipMemsetAsync(d_status, 0, n, s));
-        HIP_TRY(hipMemsetAsync(d_blocked, 0, n, s));
         int iters = 0;
         for (;;) {
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UNKNOWN], 0, sizeof(unsigned long long), s));
@@ -464,7 +503,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes,
+    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->fused_tasks,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
@@ -486,6 +525,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "fused_max")) {
+        if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
+        ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);
     } else if (!strcmp(name, "bs_col_chunk")) {
         if (value < BS_COL_TILE || value > (1 << 24))
             return fail(UMI_ERR_ARG, "bs_col_chunk outside %d..%d", BS_COL_TILE, 1 << 24);

@@ -413,6 +413,137 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
         atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
 }
 
+// ---- fused small-bucket kernel (n <= 64*RL): one wave per bucket ------------------
+// A bucket's rows sit one (or two) per lane; column j's key, nmask and threshold are
+// broadcast with v_readlane (j is wave-uniform), the exact reference distance
+// (bitset.rs:85-87) decides each pair, the permitted in-edges of a row are kept as bit
+// masks in registers, and the collapse runs in-wave: Gauss-Seidel min-label sweeps in
+// rank order for directional (directional.rs:30-54,78-88), the sequential root loop for
+// adjacency (adjacency.rs:52-60).  No LDS, no atomics, no edge list: 24 B/entry in,
+// 4 B/entry out, so this kernel streams at whatever HBM/launch latency allows.
+struct SmallTaskDev {
+    uint32_t start;
+    uint32_t n;
+};
+static_assert(sizeof(SmallTaskDev) == sizeof(SmallTask), "task layout");
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int RL, bool HAS_N, int MODE>
+__global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
+                                                           const uint64_t *__restrict__ nmask,
+                                                           const int32_t *__restrict__ freq,
+                                                           const int32_t *__restrict__ thr,
+                                                           const SmallTaskDev *__restrict__ tasks,
+                                                           uint32_t n_tasks,
+                                                           uint32_t *__restrict__ label,
+                                                           uint8_t *__restrict__ status, int k,
+                                                           int32_t adj_max_freq)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = wave; t < n_tasks; t += n_waves) {
+        const uint32_t start = __builtin_amdgcn_readfirstlane(tasks[t].start);
+        const int n = (int)__builtin_amdgcn_readfirstlane(tasks[t].n);
+        uint64_t key[RL], nm[RL];
+        int32_t fr[RL], th[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            const int r = lane + 64 * s;
+            const bool in_range = r < n;
+            key[s] = in_range ? keys[start + r] : 0ull;
+            nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
+            fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
+            th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+        }
+        // in[s][w]: bit jj set <=> entry j = 64w+jj may remove row (lane + 64s)
+        uint64_t in[RL][RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+#pragma unroll
+            for (int w = 0; w < RL; w++) in[s][w] = 0;
+#pragma unroll
+        for (int w = 0; w < RL; w++) {
+            const int jn = min(64, n - 64 * w);
+            for (int jj = 0; jj < jn; jj++) {
+                const uint64_t kj = readlane64(key[w], jj);
+                const uint64_t nj = HAS_N ? readlane64(nm[w], jj) : 0ull;
+                const int32_t thj = __builtin_amdgcn_readlane(th[w], jj);
+                const int j = 64 * w + jj;
+#pragma unroll
+                for (int s = 0; s < RL; s++) {
+                    const uint64_t x = nm[s] ^ nj;
+                    const int bcx = __builtin_popcountll(x | (key[s] ^ kj)) -
+                                    (HAS_N ? __builtin_popcountll(x) / 3 : 0);
+                    bool e = (bcx / 2) <= k && (lane + 64 * s) != j;
+                    if (MODE == MODE_DIRECTIONAL)
+                        e = e && fr[s] <= thj; // naive.rs:31 with max_freq = threshold(start)
+                    else
+                        e = e && fr[s] <= adj_max_freq && (lane + 64 * s) > j;
+                    in[s][w] |= e ? (1ull << jj) : 0ull;
+                }
+            }
+        }
+        uint32_t lab[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+        if (MODE == MODE_DIRECTIONAL) {
+            bool changed;
+            do {
+                changed = false;
+#pragma unroll
+                for (int w = 0; w < RL; w++) {
+                    const int jn = min(64, n - 64 * w);
+                    for (int jj = 0; jj < jn; jj++) {
+                        const uint32_t lj = __builtin_amdgcn_readlane(lab[w], jj);
+#pragma unroll
+                        for (int s = 0; s < RL; s++) {
+                            if (((in[s][w] >> jj) & 1ull) && lj < lab[s]) {
+                                lab[s] = lj;
+                                changed = true;
+                            }
+                        }
+                    }
+                }
+            } while (__any(changed));
+#pragma unroll
+            for (int s = 0; s < RL; s++)
+                if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
+        } else {
+            uint32_t alive[RL];
+#pragma unroll
+            for (int s = 0; s < RL; s++) alive[s] = 1u;
+#pragma unroll
+            for (int w = 0; w < RL; w++) {
+                const int jn = min(64, n - 64 * w);
+                for (int jj = 0; jj < jn; jj++) {
+                    if (__builtin_amdgcn_readlane(alive[w], jj)) { // j is a root (adjacency.rs:54)
+#pragma unroll
+                        for (int s = 0; s < RL; s++) {
+                            if (((in[s][w] >> jj) & 1ull) && alive[s]) {
+                                alive[s] = 0u;
+                                lab[s] = (uint32_t)(64 * w + jj);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < RL; s++)
+                if (lane + 64 * s < n) {
+                    label[start + lane + 64 * s] = start + lab[s];
+                    status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
+                }
+        }
+    }
+}
+
 // ---- collapse: directed min-rank label propagation ---------------------------
 __global__ __launch_bounds__(256) void hook_kernel(const uint2 *__restrict__ edges,
                                                    const unsigned long long *counters,
@@ -617,6 +748,39 @@ hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool 
         else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, s);
     } else {
         launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, s);
+    }
+    return hipGetLastError();
+}
+
+namespace {
+template <int RL, bool HAS_N>
+void launch_small_rl(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                     const int32_t *thr, const SmallTask *tasks, uint32_t n_tasks, uint32_t *label,
+                     uint8_t *status, int k, int mode, int32_t adj_max_freq, hipStream_t s)
+{
+    const uint32_t blocks = grid_for((uint64_t)n_tasks * 64, 256, 256 * 8);
+    const SmallTaskDev *t = (const SmallTaskDev *)tasks;
+    if (mode == MODE_DIRECTIONAL)
+        small_bucket_kernel<RL, HAS_N, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
+            keys, nmask, freq, thr, t, n_tasks, label, status, k, adj_max_freq);
+    else
+        small_bucket_kernel<RL, HAS_N, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
+            keys, nmask, freq, thr, t, n_tasks, label, status, k, adj_max_freq);
+}
+} // namespace
+
+hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                                const int32_t *thr, const SmallTask *tasks, uint32_t n_tasks,
+                                int rows_per_lane, uint32_t *label, uint8_t *status, int k, int mode,
+                                int32_t adj_max_freq, hipStream_t s)
+{
+    if (n_tasks == 0) return hipSuccess;
+    if (rows_per_lane == 1) {
+        if (nmask) launch_small_rl<1, true>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
+        else launch_small_rl<1, false>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
+    } else {
+        if (nmask) launch_small_rl<2, true>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
+        else launch_small_rl<2, false>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
     }
     return hipGetLastError();
 }
