@@ -1,0 +1,142 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties
+(the oracle is O(n^2) scalar code: hours at these sizes).
+
+Properties of the reference semantics (src/algo/directional.rs:30-91 over
+src/data/naive.rs:26-40) that hold for any input:
+  P1  kept[v] == (root[v] == v); root[root[v]] == root[v]; root[v] <= v; same bucket.
+  P2  fixed point of the min-rank recurrence: root[v] == min(v, min over permitted in-edges
+      u->v of root[u]), checked exactly on a random sample of v against ALL entries of
+      the bucket (numpy popcount over the whole key array per sampled v).
+  P3  k = 0 keeps every entry; adjacency (reference max_freq 0) keeps every entry.
+  P4  bucket independence: a bucket deduplicated alone gives the same mask as inside the
+      batch; the result does not depend on where the bucket sits in the batch.
+  P5  an oracle run on a subsample of whole buckets agrees bit for bit."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    yield c
+    c.close()
+
+
+def popcount64(x):
+    x = x - ((x >> np.uint64(1)) & np.uint64(0x5555555555555555))
+    x = (x & np.uint64(0x3333333333333333)) + ((x >> np.uint64(2)) & np.uint64(0x3333333333333333))
+    x = (x + (x >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    return (x * np.uint64(0x0101010101010101)) >> np.uint64(56)
+
+
+def thr_of(freq, p):
+    return (np.float32(p) * (freq + 1).astype(np.float32)).astype(np.int32)
+
+
+def check_structure(kept, root, off):
+    n = len(kept)
+    idx = np.arange(n, dtype=np.uint32)
+    assert ((kept == 1) == (root == idx)).all()
+    assert (root[root] == root).all()
+    assert (root <= idx).all()
+    bucket = np.searchsorted(off.astype(np.int64), idx.astype(np.int64), side="right")
+    assert (bucket[root] == bucket).all()
+
+
+def check_fixed_point(keys, freq, root, off, k, p, sample, rng):
+    """Exact recurrence check for sampled entries (N-free keys: dist = popcount(xor)/2)."""
+    thr = thr_of(freq, p)
+    for v in sample:
+        b = np.searchsorted(off.astype(np.int64), v, side="right") - 1
+        s, e = int(off[b]), int(off[b + 1])
+        d = popcount64(keys[s:e] ^ keys[v]) // np.uint64(2)
+        ok = (d <= k) & (freq[v] <= thr[s:e])
+        ok[v - s] = False
+        cand = root[s:e][ok]
+        want = min(int(v), int(cand.min())) if len(cand) else int(v)
+        assert int(root[v]) == want, (v, int(root[v]), want)
+
+
+def test_config2_one_million_reads_single_position(ctx):
+    from umi_collapse_rs_amd import synth
+    st = synth.config2(seed=2, n_reads=1_000_000, umi_len=12)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    assert len(keys) > 950_000
+    kept, root, stats = ctx.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    assert stats["n_pairs"] == len(keys) * (len(keys) - 1) // 2
+    assert stats["n_kept"] == int(kept.sum())
+    check_structure(kept, root, off)
+    rng = np.random.default_rng(0)
+    sample = np.concatenate([rng.choice(len(keys), 150, replace=False),
+                             np.nonzero(kept == 0)[0][:50], np.nonzero(kept == 1)[0][-50:]])
+    check_fixed_point(keys, freq, root, off, 1, 0.5, sample, rng)
+    # P3
+    kept0, root0, _ = ctx.dedup_batch(keys, None, freq, off, 12, k=0)
+    assert kept0.all() and (root0 == np.arange(len(keys))).all()
+    kept_adj, _, _ = ctx.dedup_batch(keys, None, freq, off, 12, k=1, algo=1)
+    assert kept_adj.all()
+    # the popcount tile kernel on the same input gives the same answer as the bit-sliced one
+    import umi_collapse_rs_amd as umi
+    c2 = umi.Context(0)
+    c2.set_option("bitslice", 0)
+    try:
+        kept2, root2, _ = c2.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    finally:
+        c2.close()
+    assert (kept2 == kept).all() and (root2 == root).all()
+
+
+def test_config3_many_small_buckets(ctx):
+    from umi_collapse_rs_amd import synth
+    st = synth.config3(seed=3, n_reads=10_000_000, n_positions=100_000, umi_len=12)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    assert len(off) - 1 == 100_000
+    kept, root, stats = ctx.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    check_structure(kept, root, off)
+    # P5: oracle on every 97th bucket
+    pick = np.arange(0, 100_000, 97)
+    for b in pick:
+        s, e = int(off[b]), int(off[b + 1])
+        ok, oroot, _ = orc.dedup_batch(keys[s:e], None, freq[s:e], [0, e - s], 12, 1)
+        assert (kept[s:e] == ok).all() and (root[s:e] - s == oroot).all(), b
+    # P4: reversed bucket order gives the same per-bucket masks
+    sizes = np.diff(off.astype(np.int64))
+    order = np.arange(len(sizes))[::-1]
+    roff = np.zeros(len(off), np.uint64)
+    roff[1:] = np.cumsum(sizes[order])
+    gidx = np.concatenate([np.arange(off[b], off[b + 1], dtype=np.int64) for b in order[:2000]])
+    n_sub = len(gidx)
+    sub_off = roff[:2001]
+    kept_r, _, _ = ctx.dedup_batch(keys[gidx], None, freq[gidx], sub_off, 12, k=1)
+    assert (kept_r == kept[gidx]).all()
+    assert n_sub == int(sub_off[-1])
+
+
+def test_config5_shape_20bp_k2(ctx):
+    from umi_collapse_rs_amd import synth
+    st = synth.config3(seed=5, n_reads=2_000_000, n_positions=20_000, umi_len=20)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    kept, root, stats = ctx.dedup_batch(keys, None, freq, off, 20, k=2, percentage=0.5)
+    check_structure(kept, root, off)
+    for b in range(0, 20_000, 53):
+        s, e = int(off[b]), int(off[b + 1])
+        ok, oroot, _ = orc.dedup_batch(keys[s:e], None, freq[s:e], [0, e - s], 20, 2)
+        assert (kept[s:e] == ok).all() and (root[s:e] - s == oroot).all(), b
+    # one large 20-bp bucket (bit-sliced 64-bit-key path) with planted clusters
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 4, (3000, 20), dtype=np.uint8)
+    reps = rng.integers(1, 12, 3000)
+    reads = np.repeat(base, reps, axis=0)
+    mut = rng.random(reads.shape) < 0.02
+    reads = np.where(mut, (reads + rng.integers(1, 4, reads.shape)) & 3, reads).astype(np.uint8)
+    st2 = synth.stage(np.zeros(len(reads), np.int64), synth.bases_to_keys(reads))
+    k2, f2, o2 = st2["keys"], st2["freq"], st2["bucket_off"]
+    assert len(k2) > 4096
+    kept2, root2, _ = ctx.dedup_batch(k2, None, f2, o2, 20, k=2)
+    ok, oroot, _ = orc.dedup_batch(k2, None, f2, o2, 20, 2)
+    assert (kept2 == ok).all() and (root2 == oroot).all()
