@@ -9,7 +9,7 @@ LIB := $(PKG)/libumihip.so
 SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_api.cpp
 HDRS := $(CSRC)/umihip_internal.h include/umihip.h
 
-all: $(LIB) oracle
+all: $(LIB) oracle cpptest
 
 $(LIB): $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS)
@@ -22,9 +22,14 @@ asm: $(CSRC)/umihip_kernels.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/umihip_kernels.s -x hip $(CSRC)/umihip_kernels.hip \
 	    -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || (cat build/resource_usage.txt; false)
 
+cpptest: $(LIB) oracle tests/cpp/test_host.cpp $(PKG)/host/umi_collapse.hpp
+	mkdir -p build
+	g++ -O2 -std=c++17 -Wall -Wextra -o build/test_host tests/cpp/test_host.cpp \
+	    -L$(PKG) -lumihip -Loracle -lumi_oracle -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
+
 clean:
 	rm -f $(LIB)
 	rm -rf build
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle asm clean
+.PHONY: all oracle asm clean cpptest
