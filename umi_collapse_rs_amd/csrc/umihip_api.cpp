@@ -85,7 +85,7 @@ struct Plan {
     }
 };
 
-constexpr int MAX_ROUNDS_PER_SYNC = 4;
+constexpr int MAX_ROUNDS_PER_SYNC = 16; // rounds enqueued between two host checks (4, 8, 16, 16, ...)
 constexpr int MAX_ROUNDS = 1 << 20;
 constexpr uint32_t BIG_COL_CHUNK = 16 * COL_TILE; // columns per big task
 
@@ -390,18 +390,18 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         if (n_edges) {
             uint32_t *d_changed = ctx->changed.as<uint32_t>();
             int rounds = 0;
+            int batch = 4;
             for (;;) {
                 HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
-                for (int r = 0; r < MAX_ROUNDS_PER_SYNC; r++)
+                for (int r = 0; r < batch; r++)
                     HIP_TRY(launch_prop_round(ctx->edges.as<uint2>(), d_cnt, cap_used,
                                               ctx->label.as<uint32_t>(), n, d_changed, r,
                                               (uint32_t)n_edges, s));
-                HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed,
-                                       sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC,
+                HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch,
                                        hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 bool done = false;
-                for (int r = 0; r < MAX_ROUNDS_PER_SYNC; r++) {
+                for (int r = 0; r < batch; r++) {
                     rounds++;
                     if (ctx->h_changed[r] == 0) {
                         done = true;
@@ -410,6 +410,7 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                 }
                 if (done) break;
                 if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
+                batch = std::min(2 * batch, MAX_ROUNDS_PER_SYNC);
             }
             st.n_rounds = (uint32_t)rounds;
         }
