@@ -218,7 +218,12 @@ def main():
             "roofline": {
                 "bound": "valu", "kernel": "bs_pair_kernel (bit-sliced all-pairs filter)",
                 "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
-                "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": None,
+                "frac": achieved / VALU_PEAK_TLANEOPS,
+                # fabric-side bytes of one pair-kernel launch at config 2 from the PMC passes in
+                # profiles/r01_config2_pmc_fetch_write_summary.csv ((FETCH_SIZE+WRITE_SIZE)*1024,
+                # uncorrected: 4 B/lane accesses, see profiles/README.md); other shapes: null
+                "traffic": 244.0e6 if (args.config == 2 and args.reads == 1_000_000
+                                        and args.umi_len == 12 and args.k == 1) else None,
                 "ops_per_pair": opp, "pairs_per_launch": w_local,
                 "kernel_ms": pair_ms,
                 "note": "integer VALU-bound (0 algorithmic HBM bytes per pair, LDS-staged "
