@@ -9,7 +9,16 @@ LIB := $(PKG)/libumihip.so
 SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_api.cpp
 HDRS := $(CSRC)/umihip_internal.h include/umihip.h
 
-all: $(LIB) oracle cpptest
+CLI := $(PKG)/bin/umicollapse
+
+all: $(LIB) oracle cpptest $(CLI)
+
+$(CLI): $(LIB) $(PKG)/host/umicollapse_main.cpp $(PKG)/host/bam.hpp $(PKG)/host/bgzf.hpp include/umihip.h
+	mkdir -p $(PKG)/bin
+	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/umicollapse_main.cpp -L$(PKG) -lumihip -lz -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/..'
+
+cli: $(CLI)
 
 $(LIB): $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS)
@@ -28,8 +37,8 @@ cpptest: $(LIB) oracle tests/cpp/test_host.cpp $(PKG)/host/umi_collapse.hpp
 	    -L$(PKG) -lumihip -Loracle -lumi_oracle -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(CLI)
 	rm -rf build
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle asm clean cpptest
+.PHONY: all oracle asm clean cpptest cli

@@ -1,0 +1,143 @@
+// BAM container view over a decompressed BGZF stream: header passthrough and zero-copy
+// record accessors.  Stands in for the rust-htslib Reader/Record calls of
+// src/deduplicate_sam.rs:78-144 and src/utils/read.rs:56-111 ("next" row N1/N2).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace umi {
+namespace bam {
+
+struct FormatError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline int32_t rd_i32(const uint8_t *p)
+{
+    int32_t v;
+    std::memcpy(&v, p, 4);
+    return v;
+}
+inline uint16_t rd_u16(const uint8_t *p)
+{
+    uint16_t v;
+    std::memcpy(&v, p, 2);
+    return v;
+}
+
+// One alignment record inside the decompressed buffer (block_size prefix included in
+// [begin, end) so that a survivor can be copied out verbatim).
+struct Record {
+    const uint8_t *begin = nullptr;
+    const uint8_t *end = nullptr;
+    const uint8_t *body() const { return begin + 4; }
+    int32_t tid() const { return rd_i32(body()); }
+    int32_t pos() const { return rd_i32(body() + 4); }
+    uint8_t l_read_name() const { return body()[8]; }
+    uint8_t mapq() const { return body()[9]; }
+    uint16_t n_cigar() const { return rd_u16(body() + 12); }
+    uint16_t flag() const { return rd_u16(body() + 14); }
+    int32_t l_seq() const { return rd_i32(body() + 16); }
+    int32_t mtid() const { return rd_i32(body() + 20); }
+    const uint8_t *qname() const { return body() + 32; }
+    size_t qname_len() const { return l_read_name() ? (size_t)l_read_name() - 1 : 0; } // without the NUL
+    const uint8_t *cigar() const { return qname() + l_read_name(); }
+    const uint8_t *seq() const { return cigar() + 4 * (size_t)n_cigar(); }
+    const uint8_t *qual() const { return seq() + ((size_t)l_seq() + 1) / 2; }
+    bool is_unmapped() const { return flag() & 0x4; }
+    bool is_reverse() const { return flag() & 0x10; }
+    bool is_paired() const { return flag() & 0x1; }
+    bool is_last_in_template() const { return flag() & 0x80; }
+
+    // utils::get_unclipped_pos (src/utils/mod.rs:96-104) over rust-htslib 0.49's
+    // CigarStringView::{pos,end_pos,leading_*,trailing_*}.  That crate's source is not in the
+    // reference tree: restated from its documented behaviour (clips counted only at the very
+    // ends: H, or S next to a terminal H) -- PARITY UNPINNED.
+    int64_t unclipped_pos() const
+    {
+        const uint8_t *c = cigar();
+        const int n = n_cigar();
+        auto op = [&](int i) { uint32_t v; std::memcpy(&v, c + 4 * i, 4); return v & 0xf; };
+        auto len = [&](int i) { uint32_t v; std::memcpy(&v, c + 4 * i, 4); return (int64_t)(v >> 4); };
+        if (is_reverse()) {
+            int64_t end_pos = pos();
+            for (int i = 0; i < n; i++) {
+                const uint32_t o = op(i);
+                if (o == 0 || o == 2 || o == 3 || o == 7 || o == 8) end_pos += len(i); // M D N = X
+            }
+            int64_t soft = 0, hard = 0;
+            if (n > 0) {
+                if (op(n - 1) == 4) soft = len(n - 1);
+                else if (op(n - 1) == 5) {
+                    hard = len(n - 1);
+                    if (n > 1 && op(n - 2) == 4) soft = len(n - 2);
+                }
+            }
+            return end_pos - 1 + soft + hard;
+        }
+        int64_t soft = 0, hard = 0;
+        if (n > 0) {
+            if (op(0) == 4) soft = len(0);
+            else if (op(0) == 5) {
+                hard = len(0);
+                if (n > 1 && op(1) == 4) soft = len(1);
+            }
+        }
+        return (int64_t)pos() - soft - hard;
+    }
+
+    // UcSAMRead::new (src/utils/read.rs:56-63): (sum(qual as f32) / seq_len as f32) as i32
+    int32_t avg_qual() const
+    {
+        volatile float sum = 0.0f;
+        const uint8_t *q = qual();
+        const int32_t n = l_seq();
+        for (int32_t i = 0; i < n; i++) sum = sum + (float)q[i];
+        volatile float avg = sum / (float)n;
+        float v = avg;
+        if (v != v) return 0;
+        if (v >= 2147483648.0f) return INT32_MAX;
+        if (v <= -2147483648.0f) return INT32_MIN;
+        return (int32_t)v;
+    }
+};
+
+struct File {
+    std::vector<uint8_t> data; // whole decompressed stream
+    size_t header_len = 0;     // magic .. end of the reference list: copied verbatim to the output
+                               // (Header::from_template, deduplicate_sam.rs:357-362)
+    int32_t n_ref = 0;
+    std::vector<Record> records;
+
+    void parse()
+    {
+        const uint8_t *p = data.data(), *e = p + data.size();
+        if (data.size() < 12 || std::memcmp(p, "BAM\1", 4) != 0) throw FormatError("Invalid input path: not a BAM file");
+        const int32_t l_text = rd_i32(p + 4);
+        const uint8_t *q = p + 8 + l_text;
+        if (q + 4 > e) throw FormatError("truncated BAM header");
+        n_ref = rd_i32(q);
+        q += 4;
+        for (int32_t r = 0; r < n_ref; r++) {
+            if (q + 4 > e) throw FormatError("truncated BAM header");
+            const int32_t l_name = rd_i32(q);
+            q += 4 + l_name + 4;
+        }
+        if (q > e) throw FormatError("truncated BAM header");
+        header_len = (size_t)(q - p);
+        while (q < e) {
+            if (q + 4 > e) throw FormatError("Failed to parse record");
+            const int32_t bs = rd_i32(q);
+            if (bs < 32 || q + 4 + bs > e) throw FormatError("Failed to parse record");
+            records.push_back({q, q + 4 + bs});
+            q += 4 + bs;
+        }
+    }
+};
+
+} // namespace bam
+} // namespace umi

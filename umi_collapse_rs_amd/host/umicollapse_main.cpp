@@ -1,0 +1,303 @@
+// `umicollapse`: the reference's command-line surface (src/cli.rs:7-77, src/main.rs:17-103)
+// over the MI355X hot path.  BAM in -> read staging (src/deduplicate_sam.rs:93-177) ->
+// ONE batched GPU call for every alignment position (replaces the loop :207-233) -> BAM out.
+//
+// "Next" rows N1/N2 of SURVEY.md 8f.  Deterministic where the reference is not: buckets and
+// freq ties follow first appearance in the input (canonical determinisation).
+// Not implemented, as in / beyond the reference: --mode fastq and --tag (unfinished in the
+// reference: main.rs:49-50, deduplicate_sam.rs:236-239), --paired (N4), --two-pass, --algo cc.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/umihip.h"
+#include "bam.hpp"
+#include "bgzf.hpp"
+
+namespace {
+
+struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
+    std::string mode = "bam", input, output, algo = "dir", merge, data = "ngrambktree";
+    int k = 1;
+    size_t umi_length = 0;
+    float percentage = 0.5f;
+    unsigned num_threads = 1;
+    uint8_t umi_sep = '_';
+    bool two_pass = false, paired = false, remove_unpaired = false, remove_chimeric = false,
+         keep_unmapped = false, track_clusters = false;
+    // development switches (not in the reference)
+    std::string dump_staging; // write the staged hot-path input here and stop before the GPU
+    bool passthrough = false; // write every mapped record back (codec round trip), no dedup
+    int device = 0;
+};
+
+[[noreturn]] void die(const std::string &msg)
+{ // the reference panics (panic = "abort")
+    std::fprintf(stderr, "umicollapse: %s\n", msg.c_str());
+    std::exit(101);
+}
+
+void usage()
+{
+    std::puts("Usage: umicollapse [OPTIONS] -i <INPUT_FILE> -o <OUITPUT_FILE>\n"
+              "  -m, --mode <MODE>        Either fastq or SAM/BAM mode [default: bam]\n"
+              "  -k <K>                   Number of substitution edits to allow [default: 1]\n"
+              "  -u <UMI_LENGTH>          The UMI length [default: 0 = autodetect]\n"
+              "  -p <PERCENTAGE>          Directional threshold percentage [default: 0.5]\n"
+              "      --num-threads <N>    Threads used in reader/writer [default: 1]\n"
+              "      --umi_sep <BYTE>     Separator byte value between UMI and read name [default: 95]\n"
+              "      --algo <ALGO>        adj or dir [default: dir]\n"
+              "      --merge <MERGE>      any, avgqual or mapqual [default: mapqual in bam mode]\n"
+              "      --data <DATA>        accepted and ignored, as in the reference: Naive semantics\n"
+              "      --keep-unmapped      Keep unmapped reads\n"
+              "      --two-pass --paired --remove-unpaired --remove-chimeric --tag   (see header)\n"
+              "      --device <ID>        GPU to use [default: 0]");
+}
+
+Cli parse(int argc, char **argv)
+{
+    Cli c;
+    auto need = [&](int &i) -> const char * {
+        if (i + 1 >= argc) die(std::string("a value is required for '") + argv[i] + "'");
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-m" || a == "--mode") c.mode = need(i);
+        else if (a == "-i") c.input = need(i);
+        else if (a == "-o") c.output = need(i);
+        else if (a == "-k") c.k = std::atoi(need(i));
+        else if (a == "-u") c.umi_length = (size_t)std::atol(need(i));
+        else if (a == "-p") c.percentage = std::strtof(need(i), nullptr);
+        else if (a == "--num-threads") c.num_threads = (unsigned)std::atoi(need(i));
+        else if (a == "--umi_sep") c.umi_sep = (uint8_t)std::atoi(need(i)); // a number, cli.rs:31-32
+        else if (a == "--algo") c.algo = need(i);
+        else if (a == "--merge") c.merge = need(i);
+        else if (a == "--data") c.data = need(i);
+        else if (a == "--two-pass") c.two_pass = true;
+        else if (a == "--paired") c.paired = true;
+        else if (a == "--remove-unpaired") c.remove_unpaired = true;
+        else if (a == "--remove-chimeric") c.remove_chimeric = true;
+        else if (a == "--keep-unmapped") c.keep_unmapped = true;
+        else if (a == "--tag") c.track_clusters = true;
+        else if (a == "--dump-staging") c.dump_staging = need(i);
+        else if (a == "--passthrough") c.passthrough = true;
+        else if (a == "--device") c.device = std::atoi(need(i));
+        else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
+        else die("unexpected argument '" + a + "'");
+    }
+    if (c.input.empty() || c.output.empty()) { usage(); die("-i and -o are required"); }
+    return c;
+}
+
+struct Entry { // one (alignment key, UMI): ReadFreq of src/utils/read_freq.rs + its key
+    uint64_t key, nmask;
+    int32_t freq;
+    int32_t score;  // avg qual or mapq of the representative
+    uint32_t rep;   // record index of the representative read
+    uint32_t bucket;
+};
+
+struct KeyHash {
+    size_t operator()(const std::pair<uint64_t, uint64_t> &k) const
+    {
+        uint64_t x = k.first * 0x9E3779B97F4A7C15ull ^ (k.second + 0x7F4A7C15u);
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(x ^ (x >> 32));
+    }
+};
+
+// UcSAMRead::get_umi_length (read.rs:65-75,87-94): first separator followed by a base
+// (caseless [ATCGN]), length of that run.
+size_t detect_umi_length(const uint8_t *q, size_t n, uint8_t sep)
+{
+    auto is_base = [](uint8_t ch) {
+        switch (ch | 0x20) { case 'a': case 't': case 'c': case 'g': case 'n': return true; default: return false; }
+    };
+    for (size_t i = 0; i + 1 < n; i++)
+        if (q[i] == sep && is_base(q[i + 1])) {
+            size_t j = i + 1;
+            while (j < n && is_base(q[j])) j++;
+            return j - i - 1;
+        }
+    die("No UMI group found in pattern match");
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Cli args = parse(argc, argv);
+    const double t_start = now_s();
+    if (args.merge.empty()) args.merge = args.mode == "fastq" ? "avgqual" : "mapqual"; // main.rs:33-39
+    if (args.track_clusters && args.two_pass) die("Cannot track clusters with the two pass algorithm!");
+    if (args.paired && args.keep_unmapped) die("Cannot keep unmapped reads with paired-end reads!");
+    if (args.mode == "fastq") die("fastq mode is not implemented (nor in the reference: main.rs:49-50)");
+    if (args.mode != "bam" && args.mode != "sam") return 0; // main.rs:49-95: nothing happens
+    if (args.paired) die("--paired is not implemented in this build (SURVEY.md 8f N4)");
+    if (args.track_clusters) die("--tag is not implemented (unfinished in the reference: deduplicate_sam.rs:236-239)");
+    int algo, merge;
+    if (args.algo == "dir") algo = UMI_ALGO_DIRECTIONAL;
+    else if (args.algo == "adj") algo = UMI_ALGO_ADJACENCY;
+    else die("Invalid algorithm combination: " + args.algo + " , " + args.merge + " and " + args.data); // main.rs:86-91
+    if (args.merge == "any") merge = 0;
+    else if (args.merge == "avgqual") merge = 1;
+    else if (args.merge == "mapqual") merge = 2;
+    else die("Invalid algorithm combination: " + args.algo + " , " + args.merge + " and " + args.data);
+
+    try {
+        // ---- read: BGZF inflate (threaded) + BAM parse
+        umi::bam::File in;
+        in.data = umi::bgzf::decompress(umi::bgzf::read_file(args.input), args.num_threads);
+        in.parse();
+        const double t_read = now_s();
+
+        // ---- staging: deduplicate_sam.rs:93-177
+        size_t total_read_count = 0, unmapped = 0;
+        size_t umi_length = args.umi_length;
+        std::vector<uint32_t> out_records; // records written before dedup (--keep-unmapped, :104-106)
+        std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> bucket_of; // Align -> bucket
+        std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // per bucket: key -> entry
+        std::vector<std::vector<uint32_t>> bucket_entries;
+        std::vector<Entry> entries;
+        std::vector<uint8_t> umi_buf;
+        for (uint32_t ri = 0; ri < in.records.size(); ri++) {
+            const umi::bam::Record &r = in.records[ri];
+            total_read_count++;
+            if (r.is_unmapped()) { // :102-108
+                unmapped++;
+                if (args.keep_unmapped || args.passthrough) out_records.push_back(ri);
+                continue;
+            }
+            if (args.passthrough) { out_records.push_back(ri); continue; }
+            // Alignment{strand, coord, ref} (:141-145); equality on tid == equality on the name
+            const int64_t coord = r.unclipped_pos();
+            const std::pair<uint64_t, uint64_t> akey((uint64_t)coord,
+                                                     ((uint64_t)(uint32_t)r.tid() << 1) | (r.is_reverse() ? 1u : 0u));
+            auto it = bucket_of.find(akey);
+            uint32_t b;
+            if (it == bucket_of.end()) {
+                b = (uint32_t)bucket_entries.size();
+                bucket_of.emplace(akey, b);
+                bucket_entries.emplace_back();
+                umi_index.emplace_back();
+            } else {
+                b = it->second;
+            }
+            const uint8_t *q = r.qname();
+            const size_t qn = r.qname_len();
+            if (umi_length == 0) umi_length = detect_umi_length(q, qn, args.umi_sep); // :154-156
+            const uint8_t *sp = (const uint8_t *)std::memchr(q, args.umi_sep, qn);    // read.rs:100
+            if (!sp) die("failed to get the umi");
+            const size_t at = (size_t)(sp - q) + 1;
+            if (at + umi_length > qn) die("UMI runs past the end of the read name");
+            if (umi_length == 0) die("Empty UMI sequence extracted");
+            uint64_t key = 0, nmask = 0;
+            if (umi_encode_umis(q + at, 1, (int)umi_length, &key, &nmask) != UMI_OK) die(umi_last_error());
+            const int32_t score = merge == 2 ? (int32_t)r.mapq() : r.avg_qual();
+            auto &idx = umi_index[b];
+            auto e = idx.find(key);
+            if (e == idx.end()) { // Vacant :161-163
+                idx.emplace(key, (uint32_t)entries.size());
+                bucket_entries[b].push_back((uint32_t)entries.size());
+                entries.push_back({key, nmask, 1, score, ri, b});
+            } else { // Occupied :164-175
+                Entry &en = entries[e->second];
+                const bool keep_existing = merge == 0 ? true : en.score >= score; // merge/mod.rs:21,35,49
+                en.freq += 1;
+                if (!keep_existing) { en.rep = ri; en.score = score; }
+            }
+        }
+        const double t_stage0 = now_s();
+        std::fprintf(stderr, "UMI collapsing reading finished in %.3f seconds\n", t_stage0 - t_start); // :178-183
+
+        // canonical rank order inside each bucket: stable freq-descending (directional.rs:67-72)
+        const size_t n = entries.size(), nb = bucket_entries.size();
+        std::vector<uint64_t> keys(n), nmask(n), off(nb + 1, 0);
+        std::vector<int32_t> freq(n);
+        std::vector<uint32_t> rep(n);
+        bool any_n = false;
+        size_t w = 0, max_umi = 0;
+        for (size_t b = 0; b < nb; b++) {
+            auto &v = bucket_entries[b];
+            std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return entries[y].freq < entries[x].freq; });
+            for (uint32_t ei : v) {
+                keys[w] = entries[ei].key; nmask[w] = entries[ei].nmask; freq[w] = entries[ei].freq; rep[w] = entries[ei].rep;
+                any_n |= entries[ei].nmask != 0;
+                w++;
+            }
+            off[b + 1] = w;
+            max_umi = std::max(max_umi, v.size());
+        }
+        if (!args.dump_staging.empty()) { // test hook: staged hot-path input, no GPU touched
+            FILE *f = std::fopen(args.dump_staging.c_str(), "wb");
+            if (!f) die("cannot open " + args.dump_staging);
+            const uint64_t hdr[4] = {n, nb, umi_length, 0};
+            std::fwrite(hdr, 8, 4, f);
+            std::fwrite(keys.data(), 8, n, f); std::fwrite(nmask.data(), 8, n, f);
+            std::fwrite(freq.data(), 4, n, f); std::fwrite(rep.data(), 4, n, f);
+            std::fwrite(off.data(), 8, nb + 1, f);
+            std::fclose(f);
+            return 0;
+        }
+
+        // ---- the hot path: one batched call replaces the bucket loop :207-233
+        std::vector<uint8_t> kept(n + 1, 0);
+        umi_stats st;
+        std::memset(&st, 0, sizeof(st));
+        double t_gpu0 = now_s(), t_gpu1 = t_gpu0;
+        if (!args.passthrough && n) {
+            umi_ctx *ctx = nullptr;
+            if (umi_ctx_create(args.device, &ctx) != UMI_OK) die(umi_last_error());
+            t_gpu0 = now_s();
+            if (umi_dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
+                                (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
+                                kept.data(), nullptr, &st) != UMI_OK)
+                die(umi_last_error());
+            t_gpu1 = now_s();
+            umi_ctx_destroy(ctx);
+        }
+        for (size_t i = 0; i < n; i++)
+            if (kept[i]) out_records.push_back(rep[i]); // :227-231, in rank order per bucket
+
+        // ---- write: header verbatim (Header::from_template :357-362) + surviving records verbatim
+        size_t out_len = in.header_len;
+        for (uint32_t ri : out_records) out_len += (size_t)(in.records[ri].end - in.records[ri].begin);
+        std::vector<uint8_t> out(out_len);
+        std::memcpy(out.data(), in.data.data(), in.header_len);
+        size_t o = in.header_len;
+        for (uint32_t ri : out_records) {
+            const size_t len = (size_t)(in.records[ri].end - in.records[ri].begin);
+            std::memcpy(out.data() + o, in.records[ri].begin, len);
+            o += len;
+        }
+        umi::bgzf::compress_to_file(args.output, out.data(), out.size(), args.num_threads);
+        const double t_end = now_s();
+
+        // counters of deduplicate_sam.rs:243-268
+        std::fprintf(stderr, "Number of input reads: %zu\n", total_read_count);
+        std::fprintf(stderr, "Number of removed unmapped reads: %zu\n", unmapped);
+        std::fprintf(stderr, "Number of unique alignment positions: %zu\n", nb);
+        std::fprintf(stderr, "Number of UMIs: %zu\n", n);
+        std::fprintf(stderr, "Average number of UMIs per alignment position: %g\n", nb ? (double)n / (double)nb : 0.0);
+        std::fprintf(stderr, "Max number of UMIs over all alignment positions: %zu\n", max_umi);
+        std::fprintf(stderr, "Number of reads after deduplicating: %llu\n", (unsigned long long)st.n_kept);
+        std::fprintf(stderr,
+                     "phases: read+inflate %.3f s, staging %.3f s, hot path (H2D+GPU+D2H) %.3f s [%llu pairs], write %.3f s\n",
+                     t_read - t_start, t_stage0 - t_read, t_gpu1 - t_gpu0, (unsigned long long)st.n_pairs, t_end - t_gpu1);
+        std::fprintf(stderr, "UMI collapsing finished in %.3f seconds\n", t_end - t_start); // main.rs:97-102
+    } catch (const std::exception &e) {
+        die(e.what());
+    }
+    return 0;
+}
