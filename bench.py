@@ -92,11 +92,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; the modulo only matters when the launch is rehearsed with more
+    # ranks than GPUs (BENCH_BACKEND=gloo on a 1-GPU box)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import umi_collapse_rs_amd as umi
     from umi_collapse_rs_amd import synth
@@ -142,7 +149,7 @@ def main():
     gather_in = torch.zeros(max_n, dtype=torch.uint8, device=dev)
     gather_out = torch.zeros(max_n * world, dtype=torch.uint8, device=dev) if world > 1 else None
 
-    ctx = umi.Context(local_rank, profile=True)
+    ctx = umi.Context(dev_index, profile=True)
     for o in args.opt:
         name, val = o.split("=")
         ctx.set_option(name, int(val))
