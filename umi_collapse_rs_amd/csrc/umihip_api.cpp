@@ -76,7 +76,7 @@ struct Plan {
     // bit-sliced tasks: [0] 64-thread tiles, [1] 256-thread tiles (diagonal tiles first)
     std::vector<BsTask> bs_tasks[2];
     std::vector<PlaneTask> plane_tasks;
-    std::vector<SmallTask> fused_tasks[2]; // [0] n <= 64 (1 row per lane), [1] n <= 128
+    uint64_t n_fused = 0; // buckets left to the fused one-wave kernel
     uint64_t plane_words = 0;
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
     size_t n_bs() const
@@ -102,7 +102,8 @@ struct umi_ctx {
     uint32_t fused_max = FUSED_MAX;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
-    DevBuf bs_tasks, plane_tasks, planes, fused_tasks;
+    DevBuf bs_tasks, plane_tasks, planes;
+    Plan plan;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
     unsigned long long *h_counters = nullptr; // pinned
@@ -115,7 +116,7 @@ namespace {
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
                 int umi_len, uint32_t col_chunk, uint32_t fused_max, Plan &pl)
 {
-    for (auto &v : pl.fused_tasks) v.clear();
+    pl.n_fused = 0;
     pl.small_tasks.clear();
     pl.big_tasks.clear();
     for (auto &v : pl.bs_tasks) v.clear();
@@ -131,7 +132,7 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
         if (n < 2) continue;
         pl.n_pairs += n * (n - 1) / 2;
         if (n <= fused_max) {
-            pl.fused_tasks[n <= 64 ? 0 : 1].push_back({(uint32_t)s, (uint32_t)n});
+            pl.n_fused++;
             pl.n_pairs_eval += n * n;
         } else if (n <= small_max) {
             for (uint64_t r0 = s; r0 < e; r0 += SMALL_ROWS) {
@@ -202,6 +203,16 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                  uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats)
 {
     HIP_TRY(hipSetDevice(ctx->device));
+    // Every early return below leaves with the stream drained: work already enqueued reads
+    // caller memory (bucket_off) and workspace buffers the next call may reallocate.
+    struct DrainOnExit {
+        hipStream_t s;
+        bool armed = true;
+        ~DrainOnExit()
+        {
+            if (armed) (void)hipStreamSynchronize(s);
+        }
+    } drain{s};
     umi_stats st;
     memset(&st, 0, sizeof(st));
     st.n_umis = n;
@@ -210,11 +221,11 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     const bool key32 = umi_len <= 16;
     const bool need_pairs =
         !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
-    Plan pl;
+    const uint32_t fused_max =
+        (mode == MODE_NEIGHBOURS || !need_pairs) ? 0u : std::min<uint32_t>(ctx->fused_max, FUSED_MAX);
+    Plan &pl = ctx->plan; // vectors keep their capacity between calls
     build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
-               ctx->bs_col_chunk,
-               (mode == MODE_NEIGHBOURS || !need_pairs) ? 0u : std::min<uint32_t>(ctx->fused_max, FUSED_MAX),
-               pl);
+               ctx->bs_col_chunk, fused_max, pl);
     st.max_bucket = pl.max_bucket;
     st.n_pairs = pl.n_pairs;
     if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
@@ -232,14 +243,11 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         (rc = ctx->bs_tasks.reserve(std::max<size_t>(1, pl.n_bs()) * sizeof(BsTask))) ||
         (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
                                        sizeof(PlaneTask))) ||
-        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))) ||
-        (rc = ctx->fused_tasks.reserve(
-             std::max<size_t>(1, pl.fused_tasks[0].size() + pl.fused_tasks[1].size()) *
-             sizeof(SmallTask))))
+        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
         return rc;
     if (mode == MODE_ADJACENCY && need_pairs)
         if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
-    const size_t n_fused = pl.fused_tasks[0].size() + pl.fused_tasks[1].size();
+    const size_t n_fused = pl.n_fused;
 
     unsigned long long *d_cnt = ctx->counters.as<unsigned long long>();
     hipEvent_t *ev = ctx->ev;
@@ -248,17 +256,6 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     if (prof) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
     HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
-    if (n_fused) {
-        SmallTask *d_f = ctx->fused_tasks.as<SmallTask>();
-        if (!pl.fused_tasks[0].empty())
-            HIP_TRY(hipMemcpyAsync(d_f, pl.fused_tasks[0].data(),
-                                   pl.fused_tasks[0].size() * sizeof(SmallTask),
-                                   hipMemcpyHostToDevice, s));
-        if (!pl.fused_tasks[1].empty())
-            HIP_TRY(hipMemcpyAsync(d_f + pl.fused_tasks[0].size(), pl.fused_tasks[1].data(),
-                                   pl.fused_tasks[1].size() * sizeof(SmallTask),
-                                   hipMemcpyHostToDevice, s));
-    }
     if (mode == MODE_ADJACENCY && need_pairs) {
         HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
         HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
@@ -298,17 +295,11 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
 
     // whole small buckets, all-pairs and collapse fused, straight to label[] / status[]
     if (n_fused) {
-        const SmallTask *d_f = ctx->fused_tasks.as<SmallTask>();
-        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(), d_f,
-                                     (uint32_t)pl.fused_tasks[0].size(), 1,
-                                     ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
-                                     adj_max_freq, s));
         HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
-                                     d_f + pl.fused_tasks[0].size(),
-                                     (uint32_t)pl.fused_tasks[1].size(), 2,
+                                     ctx->boff.as<uint64_t>(), (uint32_t)n_buckets, fused_max,
                                      ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
                                      adj_max_freq, s));
-        st.n_pair_launches += (pl.fused_tasks[0].empty() ? 0 : 1) + (pl.fused_tasks[1].empty() ? 0 : 1);
+        st.n_pair_launches += 1;
     }
     uint64_t n_edges = 0;
     uint32_t cap_used = 0;
@@ -381,6 +372,7 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             if (ctx->h_counters[CNT_ERROR])
                 return fail(UMI_ERR_ORDER, "freq < 1 in the umi_freq map");
         }
+        drain.armed = false; // synchronised above
         if (stats) *stats = st;
         return UMI_OK;
     }
@@ -454,6 +446,7 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
         HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
     }
+    drain.armed = false; // synchronised above
     if (stats) *stats = st;
     return UMI_OK;
 }
@@ -504,7 +497,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->fused_tasks,
+    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,

@@ -46,12 +46,7 @@ struct BsTask {
     uint32_t pad;
 };
 
-// Fused small-bucket kernel: one wave owns one whole bucket.
-struct SmallTask {
-    uint32_t start; // global index of the bucket's first entry
-    uint32_t n;     // entries (<= 64 * rows_per_lane)
-};
-constexpr int FUSED_MAX = 128; // largest bucket the fused kernel takes (2 rows per lane)
+constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
 // One wave transposes 64 rows of one bucket into bit planes.
 struct PlaneTask {
@@ -110,11 +105,11 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, hipStream_t s);
 
-// all-pairs + collapse of whole small buckets in one wave each; writes label[] (and, in
-// adjacency mode, status[]) directly
+// all-pairs + collapse of whole small buckets (2..fused_max entries), one wave per bucket;
+// walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[])
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                                const int32_t *thr, const SmallTask *tasks, uint32_t n_tasks,
-                                int rows_per_lane, uint32_t *label, uint8_t *status, int k, int mode,
+                                const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
+                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k, int mode,
                                 int32_t adj_max_freq, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a

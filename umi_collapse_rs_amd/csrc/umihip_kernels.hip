@@ -421,12 +421,6 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
 // rank order for directional (directional.rs:30-54,78-88), the sequential root loop for
 // adjacency (adjacency.rs:52-60).  No LDS, no atomics, no edge list: 24 B/entry in,
 // 4 B/entry out, so this kernel streams at whatever HBM/launch latency allows.
-struct SmallTaskDev {
-    uint32_t start;
-    uint32_t n;
-};
-static_assert(sizeof(SmallTaskDev) == sizeof(SmallTask), "task layout");
-
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
 {
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
@@ -434,23 +428,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// one bucket [start, start + n), n <= 64 * RL, by the calling wave
 template <int RL, bool HAS_N, int MODE>
-__global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
-                                                           const uint64_t *__restrict__ nmask,
-                                                           const int32_t *__restrict__ freq,
-                                                           const int32_t *__restrict__ thr,
-                                                           const SmallTaskDev *__restrict__ tasks,
-                                                           uint32_t n_tasks,
-                                                           uint32_t *__restrict__ label,
-                                                           uint8_t *__restrict__ status, int k,
-                                                           int32_t adj_max_freq)
+__device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ keys,
+                                                  const uint64_t *__restrict__ nmask,
+                                                  const int32_t *__restrict__ freq,
+                                                  const int32_t *__restrict__ thr, uint32_t start,
+                                                  int n, uint32_t *__restrict__ label,
+                                                  uint8_t *__restrict__ status, int k,
+                                                  int32_t adj_max_freq)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t t = wave; t < n_tasks; t += n_waves) {
-        const uint32_t start = __builtin_amdgcn_readfirstlane(tasks[t].start);
-        const int n = (int)__builtin_amdgcn_readfirstlane(tasks[t].n);
+    {
         uint64_t key[RL], nm[RL];
         int32_t fr[RL], th[RL];
 #pragma unroll
@@ -541,6 +530,36 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
                     status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
                 }
         }
+    }
+}
+
+// Walks the bucket table itself (no task list to build or upload): wave w takes buckets
+// w, w + n_waves, ...; buckets with fewer than 2 or more than fused_max entries belong
+// to other kernels and are skipped.
+template <bool HAS_N, int MODE>
+__global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
+                                                           const uint64_t *__restrict__ nmask,
+                                                           const int32_t *__restrict__ freq,
+                                                           const int32_t *__restrict__ thr,
+                                                           const uint64_t *__restrict__ bucket_off,
+                                                           uint32_t n_buckets, uint32_t fused_max,
+                                                           uint32_t *__restrict__ label,
+                                                           uint8_t *__restrict__ status, int k,
+                                                           int32_t adj_max_freq)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t b = wave; b < n_buckets; b += n_waves) {
+        const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b + 1]);
+        const uint32_t n = end - start;
+        if (n < 2 || n > fused_max) continue;
+        if (n <= 64)
+            small_bucket_body<1, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
+                                              adj_max_freq);
+        else
+            small_bucket_body<2, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
+                                              adj_max_freq);
     }
 }
 
@@ -752,35 +771,27 @@ hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool 
     return hipGetLastError();
 }
 
-namespace {
-template <int RL, bool HAS_N>
-void launch_small_rl(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                     const int32_t *thr, const SmallTask *tasks, uint32_t n_tasks, uint32_t *label,
-                     uint8_t *status, int k, int mode, int32_t adj_max_freq, hipStream_t s)
-{
-    const uint32_t blocks = grid_for((uint64_t)n_tasks * 64, 256, 256 * 8);
-    const SmallTaskDev *t = (const SmallTaskDev *)tasks;
-    if (mode == MODE_DIRECTIONAL)
-        small_bucket_kernel<RL, HAS_N, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
-            keys, nmask, freq, thr, t, n_tasks, label, status, k, adj_max_freq);
-    else
-        small_bucket_kernel<RL, HAS_N, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
-            keys, nmask, freq, thr, t, n_tasks, label, status, k, adj_max_freq);
-}
-} // namespace
-
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                                const int32_t *thr, const SmallTask *tasks, uint32_t n_tasks,
-                                int rows_per_lane, uint32_t *label, uint8_t *status, int k, int mode,
+                                const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
+                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k, int mode,
                                 int32_t adj_max_freq, hipStream_t s)
 {
-    if (n_tasks == 0) return hipSuccess;
-    if (rows_per_lane == 1) {
-        if (nmask) launch_small_rl<1, true>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
-        else launch_small_rl<1, false>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
+    if (n_buckets == 0 || fused_max < 2) return hipSuccess;
+    const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, 256 * 8);
+    if (mode == MODE_DIRECTIONAL) {
+        if (nmask)
+            small_bucket_kernel<true, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
+                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
+        else
+            small_bucket_kernel<false, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
+                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
     } else {
-        if (nmask) launch_small_rl<2, true>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
-        else launch_small_rl<2, false>(keys, nmask, freq, thr, tasks, n_tasks, label, status, k, mode, adj_max_freq, s);
+        if (nmask)
+            small_bucket_kernel<true, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
+                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
+        else
+            small_bucket_kernel<false, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
+                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
     }
     return hipGetLastError();
 }
