@@ -26,13 +26,14 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-# Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter, k = 1): per
-# column and 32-row group, 12 bases x (2 mask ops + 1.5 sticky-counter ops) = 42 full-rate
-# 32-bit ops for 32 pairs (kernel K1b)
-def ops_per_pair(umi_len, k):
+# Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
+# and 32-row group, 2 ops per base for the mismatch planes plus the sticky counter per unit
+# of `unit` bases (0.5 / 1.5 / K+1 ops for K = 0 / 1 / >1), all full-rate 32-bit ops, for 32
+# pairs.  L = 12, k = 1, unit = 2: (24 + 9) / 32 = 1.03 (kernel K1b)
+def ops_per_pair(umi_len, k, unit=2):
     lp = 8 if umi_len <= 8 else 12 if umi_len <= 12 else 16 if umi_len <= 16 else 22
-    per_base = 2.0 + (0.5 if k == 0 else 1.5 if k == 1 else k + 1.0)
-    return lp * per_base / 32.0
+    per_unit = 0.5 if k == 0 else 1.5 if k == 1 else k + 1.0
+    return (2.0 * lp + per_unit * (lp / unit)) / 32.0
 BYTES_PER_UMI = 16   # 8 B key + 4 B freq in, 4 B label out
 
 
@@ -202,7 +203,11 @@ def main():
         pair_ms = float(np.mean([s["ms_pairs"] for s in stats]))
         coll_ms = float(np.mean([s["ms_collapse"] for s in stats]))
         s0 = stats[-1]
-        opp = ops_per_pair(args.umi_len, args.k)
+        unit = 2
+        for o in args.opt:
+            if o.startswith("bs_unit="):
+                unit = int(o.split("=")[1])
+        opp = ops_per_pair(args.umi_len, args.k, unit)
         achieved = opp * w_local / (pair_ms * 1e-3) / 1e12
         out = {
             "metric": "UMI-pair Hamming comparisons/s (12-bp UMIs, all-pairs adjacency + "

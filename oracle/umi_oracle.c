@@ -101,7 +101,8 @@ static int32_t f32_as_i32(float v)
 int32_t orc_threshold(float percentage, int32_t freq)
 {
     /* directional.rs:38 */
-    volatile float prod = percentage * (float)(freq + 1);
+    /* freq + 1 wraps in a release build of the reference (Cargo.toml:16-19) */
+    volatile float prod = percentage * (float)(int32_t)((uint32_t)freq + 1u);
     return f32_as_i32(prod);
 }
 

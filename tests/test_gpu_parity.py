@@ -131,14 +131,16 @@ def test_medium_bucket_crosses_tile_boundaries(ctx):
     check_against_oracle(ctx, keys, nm, fr, off, 8, 2)
 
 
-@pytest.mark.parametrize("bitslice", [1, 0])
-def test_tile_kernels_on_all_sizes(bitslice):
-    """small_max=0 sends every bucket through the tile kernels: the bit-sliced one
-    (bitslice=1, k<=3) or the popcount one (bitslice=0)."""
+@pytest.mark.parametrize("bitslice,unit", [(1, 2), (1, 1), (1, 3), (0, 2)])
+def test_tile_kernels_on_all_sizes(bitslice, unit):
+    """small_max=0, fused_max=0 send every bucket through the tile kernels: the bit-sliced
+    one (k<=3; counting units of 2 bases or single bases) or the popcount one."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
     c.set_option("small_max", 0)
+    c.set_option("fused_max", 0)
     c.set_option("bitslice", bitslice)
+    c.set_option("bs_unit", unit)
     try:
         rng = np.random.default_rng(43)
         keys, nm, fr, off = make_batch(rng, 40, 12, 60, err=0.05, n_frac=0.01)

@@ -189,7 +189,8 @@ class Directional:
         stack = [start_umi]
         while stack:
             u = stack.pop()
-            threshold = _f32_as_i32(self.percentage * np.float32(reads[u].freq + 1))
+            f1 = (reads[u].freq + 1 + 2 ** 31) % 2 ** 32 - 2 ** 31  # i32 wrap, as a release build
+            threshold = _f32_as_i32(self.percentage * np.float32(f1))
             near = data.remove_near(u, self.k, threshold)
             if cluster is not None:
                 cluster.extend(near)

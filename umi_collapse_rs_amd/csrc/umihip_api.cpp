@@ -100,6 +100,7 @@ struct umi_ctx {
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
     uint32_t fused_max = FUSED_MAX;
+    int bs_unit = 2;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
@@ -331,9 +332,9 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                 PairArgs b = a;
                 b.bs_tasks = a.bs_tasks + pl.bs_tasks[0].size();
                 HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
-                                        s));
+                                        ctx->bs_unit, s));
                 HIP_TRY(launch_bs_pairs(a, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
-                                        s));
+                                        ctx->bs_unit, s));
             }
             a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
             HIP_TRY(launch_pairs(a, (uint32_t)pl.big_tasks.size(), true, key32, s));
@@ -519,6 +520,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "bs_unit")) {
+        if (value < 1 || value > 3) return fail(UMI_ERR_ARG, "bs_unit must be 1, 2 or 3");
+        ctx->bs_unit = (int)value;
     } else if (!strcmp(name, "fused_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
         ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);

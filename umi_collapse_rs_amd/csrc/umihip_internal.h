@@ -102,8 +102,9 @@ inline int bs_groups_per_lane(int umi_len) { return umi_len <= 16 ? 2 : 1; }
 hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *tasks,
                                uint32_t n_tasks, uint32_t *planes, int umi_len, hipStream_t s);
 // wide: 256-thread blocks (256*G groups per tile), else 64-thread blocks
+// unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
-                           int umi_len, hipStream_t s);
+                           int umi_len, int unit, hipStream_t s);
 
 // all-pairs + collapse of whole small buckets (2..fused_max entries), one wave per bucket;
 // walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[])

@@ -40,7 +40,8 @@ template <> __device__ __forceinline__ uint64_t pad_col<uint64_t>() { return 0xF
 // src/algo/directional.rs:38.
 __device__ __forceinline__ int32_t threshold_of(float percentage, int32_t freq)
 {
-    float prod = __fmul_rn(percentage, (float)(freq + 1));
+    // freq + 1 wraps in a release build of the reference (Cargo.toml:16-19)
+    float prod = __fmul_rn(percentage, (float)(int32_t)((uint32_t)freq + 1u));
     if (prod != prod) return 0;
     if (prod >= 2147483648.0f) return 2147483647;
     if (prod <= -2147483648.0f) return (-2147483647 - 1);
@@ -301,11 +302,11 @@ __global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict
 #define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
 constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
 
-template <typename KeyT, int LP, int G, int K, int THREADS>
+template <typename KeyT, int LP, int G, int K, int THREADS, int GB>
 __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
 {
     constexpr int NP = 2 * LP;
-    static_assert(LP % 2 == 0 && NP % 4 == 0, "padded base count must be even");
+    static_assert(LP % GB == 0 && NP % 4 == 0, "padded base count must be a multiple of the unit");
     __shared__ __attribute__((aligned(16))) uint32_t cmask[BS_COL_TILE * NP];
     __shared__ EdgeStage stage;
     const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x;
@@ -362,16 +363,23 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
                 uint32_t s[K + 2]; // s[l] = rows with at least l mismatches so far (l = 1..K+1)
 #pragma unroll
                 for (int l = 0; l < K + 2; l++) s[l] = 0;
+                // mismatch mask of a unit of GB consecutive bases (any of its 2*GB code bits
+                // differs): one xor, then one bitop3 "acc | (P ^ c)" per further plane
+                auto unit_mask = [&](int u) -> uint32_t {
+                    uint32_t m = p[g][2 * GB * u] ^ cm[2 * GB * u];
 #pragma unroll
-                for (int i = 0; i < LP; i += 2) {
-                    const uint32_t ta = p[g][2 * i] ^ cm[2 * i];
-                    const uint32_t ma = BITOP3(ta, p[g][2 * i + 1], cm[2 * i + 1], TT_A | (TT_B ^ TT_C));
-                    const uint32_t tb = p[g][2 * i + 2] ^ cm[2 * i + 2];
-                    const uint32_t mb = BITOP3(tb, p[g][2 * i + 3], cm[2 * i + 3], TT_A | (TT_B ^ TT_C));
+                    for (int b = 1; b < 2 * GB; b++)
+                        m = BITOP3(m, p[g][2 * GB * u + b], cm[2 * GB * u + b], TT_A | (TT_B ^ TT_C));
+                    return m;
+                };
+                constexpr int U = LP / GB; // units per key
+#pragma unroll
+                for (int u = 0; u + 1 < U; u += 2) {
+                    const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
                     if (K == 0) {
                         s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
                     } else if (K == 1) {
-                        // two bases per step: >=2 of {s1, ma, mb} feeds s2
+                        // two units per step: >=2 of {s1, ma, mb} feeds s2
                         s[2] |= BITOP3(s[1], ma, mb, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
                         s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
                     } else {
@@ -382,6 +390,12 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
                         for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], mb, TT_A | (TT_B & TT_C));
                         s[1] |= mb;
                     }
+                }
+                if (U % 2) { // odd unit count: the last unit alone
+                    const uint32_t ma = unit_mask(U - 1);
+#pragma unroll
+                    for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
+                    s[1] |= ma;
                 }
                 uint32_t hg = ~s[K + 1] & valid[g];
                 if (diag) { // only rows before the column: keeps the self pair and i > j out
@@ -737,36 +751,45 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 
 namespace {
 template <typename KeyT, int LP, int G, int K>
-void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, hipStream_t s)
+void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, hipStream_t s)
 {
-    if (wide)
-        bs_pair_kernel<KeyT, LP, G, K, 256><<<n_tasks, 256, 0, s>>>(a);
-    else
-        bs_pair_kernel<KeyT, LP, G, K, 64><<<n_tasks, 64, 0, s>>>(a);
+    // unit = bases per counted unit: 2 by default (filter = "at most K units differ", a
+    // superset of distance <= K that verify_pair makes exact), 1 = exact base count,
+    // 3 = fewer ops but 7x the false candidates on random 12-mers (k = 1, L' % 3 == 0 only)
+    if (unit == 1) {
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, 256, 1><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, 64, 1><<<n_tasks, 64, 0, s>>>(a);
+    } else if (unit == 3 && LP % 3 == 0 && K == 1) {
+        if (wide) bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, 256, 3><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, 64, 3><<<n_tasks, 64, 0, s>>>(a);
+    } else {
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, 256, 2><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, 64, 2><<<n_tasks, 64, 0, s>>>(a);
+    }
 }
 template <typename KeyT, int LP, int G>
-void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, hipStream_t s)
+void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_tasks, wide, s); break;
-    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_tasks, wide, s); break;
-    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_tasks, wide, s); break;
-    default: launch_bs_k<KeyT, LP, G, 3>(a, n_tasks, wide, s); break;
+    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_tasks, wide, unit, s); break;
+    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_tasks, wide, unit, s); break;
+    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_tasks, wide, unit, s); break;
+    default: launch_bs_k<KeyT, LP, G, 3>(a, n_tasks, wide, unit, s); break;
     }
 }
 } // namespace
 
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
-                           int umi_len, hipStream_t s)
+                           int umi_len, int unit, hipStream_t s)
 {
     if (n_tasks == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
     if (key32) {
-        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_tasks, wide, s);
-        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_tasks, wide, s);
-        else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, s);
+        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_tasks, wide, unit, s);
+        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_tasks, wide, unit, s);
+        else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, unit, s);
     } else {
-        launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, s);
+        launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, unit, s);
     }
     return hipGetLastError();
 }

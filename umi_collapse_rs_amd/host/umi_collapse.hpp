@@ -149,7 +149,8 @@ using ClusterTracker = std::unordered_map<const BitSet *, std::vector<const BitS
 
 inline int32_t threshold(float percentage, int32_t freq)
 { // directional.rs:38, Rust `as i32` semantics
-    volatile float prod = percentage * (float)(freq + 1);
+    /* freq + 1 wraps in a release build of the reference (Cargo.toml:16-19) */
+    volatile float prod = percentage * (float)(int32_t)((uint32_t)freq + 1u);
     float v = prod;
     if (v != v) return 0;
     if (v >= 2147483648.0f) return INT32_MAX;
