@@ -189,8 +189,8 @@ int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, i
                         (unsigned long long)b);
     const uint64_t n = n_buckets ? bucket_off[n_buckets] : 0;
     if (n_buckets && bucket_off[0] != 0) return fail(UMI_ERR_ARG, "bucket_off[0] must be 0");
-    if (n >= 0xFFFFFFF0ull)
-        return fail(UMI_ERR_ARG, "%llu entries exceed the 32-bit index space of one call",
+    if (n >= 0x7FFFFFF0ull) // bit 31 of an edge endpoint is a flag
+        return fail(UMI_ERR_ARG, "%llu entries exceed the 31-bit index space of one call",
                     (unsigned long long)n);
     *n_out = n;
     return UMI_OK;

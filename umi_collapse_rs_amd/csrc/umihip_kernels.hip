@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
     }
 }
 
+// Edge list entries are (src, dst); SYM_FLAG on src marks a pair permitted in both
+// directions, stored once (entry indices stay below 2^31).
+constexpr uint32_t SYM_FLAG = 0x80000000u;
+
 // Per-block staging of emitted edges in LDS: one global atomic per flush instead of one
 // per edge (a single hot counter word saturates near 90 atomics/us on this chip).
 constexpr int EDGE_BUF = 512;
@@ -151,19 +155,26 @@ __device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
         fwd = fj <= adj_max_freq; // adjacency.rs:56
         bwd = false;              // a root only ever sees entries of larger rank
     }
-    if (fwd) emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, false);
-    if (bwd) emit_edge(st, edges, edge_dist, counters, edge_cap, gj, gi, dist, false);
+    if (fwd && bwd) // both directions permitted: one flagged entry, halves the list
+        emit_edge(st, edges, edge_dist, counters, edge_cap, gi | SYM_FLAG, gj, dist, false);
+    else if (fwd)
+        emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, false);
+    else if (bwd)
+        emit_edge(st, edges, edge_dist, counters, edge_cap, gj, gi, dist, false);
 }
 
 // Block-wide: move the staged edges to the global list.  Called by every thread.
 template <int THREADS>
 __device__ __forceinline__ void flush_edges(EdgeStage *st, uint2 *edges, uint8_t *edge_dist,
                                             unsigned long long *counters, uint32_t edge_cap,
-                                            bool with_dist)
+                                            bool with_dist, bool final)
 {
     __syncthreads();
     const unsigned int n = min(st->count, (unsigned int)EDGE_BUF);
-    if (n == 0) return; // uniform: count is stable between the two barriers
+    // Keep staging until the buffer is three quarters full: long runs of edges of one tile
+    // task stay together in the list, so the collapse's label gathers hit the same lines.
+    // (uniform: count is stable between the two barriers)
+    if (n == 0 || (!final && n < (unsigned int)(EDGE_BUF * 3 / 4))) return;
     if (threadIdx.x == 0)
         st->base = (unsigned int)min(atomicAdd(&counters[CNT_EDGES], (unsigned long long)n),
                                      (unsigned long long)0xFFFFFFFFu);
@@ -256,7 +267,8 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
                 }
             }
         }
-        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist);
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
+                             c0 + COL_TILE >= col1);
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
@@ -420,7 +432,8 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
                 }
             }
         }
-        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist);
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
+                             c0 + BS_COL_TILE >= col1);
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
@@ -587,12 +600,32 @@ __global__ __launch_bounds__(256) void hook_kernel(const uint2 *__restrict__ edg
     unsigned long long ne = counters[CNT_EDGES];
     const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
     bool any = false;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        const uint2 uv = edges[e];
-        const uint32_t lu = label[uv.x];
-        if (lu < label[uv.y]) {
-            atomicMin(&label[uv.y], lu);
-            any = true;
+    // four edges per thread per trip, all loads issued before the first use: the trip is a
+    // chain of dependent L2 round trips otherwise
+    constexpr int ILP = 4;
+    const uint32_t nth = gridDim.x * blockDim.x;
+    for (uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < E; e0 += ILP * nth) {
+        uint2 uv[ILP];
+        uint32_t lu[ILP], lv[ILP];
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            const uint32_t e = e0 + i * nth;
+            uv[i] = e < E ? edges[e] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            lu[i] = label[uv[i].x & ~SYM_FLAG];
+            lv[i] = label[uv[i].y];
+        }
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            if (lu[i] < lv[i]) {
+                atomicMin(&label[uv[i].y], lu[i]);
+                any = true;
+            } else if ((uv[i].x & SYM_FLAG) && lv[i] < lu[i]) {
+                atomicMin(&label[uv[i].x & ~SYM_FLAG], lv[i]);
+                any = true;
+            }
         }
     }
     if (any) changed[round] = 1;
