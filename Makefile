@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unused-parameter
 
 LIB := $(PKG)/libumihip.so
-SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_api.cpp
+SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_sort.hip $(CSRC)/umihip_api.cpp
 HDRS := $(CSRC)/umihip_internal.h include/umihip.h
 
 CLI := $(PKG)/bin/umicollapse

@@ -75,7 +75,9 @@ const char *umi_last_error(void);
  * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
  * bit-sliced task), "fused_max" (largest bucket handled by the fused one-wave-per-bucket
  * kernel, 0..128, default 128), "bs_unit" (bases per counted unit of the bit-sliced filter:
- * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2).
+ * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2),
+ * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
+ * cannot hold a pair within k -- same result, fewer comparisons executed).
  * Unknown name -> UMI_ERR_ARG. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
 /* 1 if this library was built with device code for gfx950 (always), for loaders */

@@ -89,6 +89,15 @@ def test_config2_one_million_reads_single_position(ctx):
     finally:
         c2.close()
     assert (kept2 == kept).all() and (root2 == root).all()
+    # key-sorted tiles with range pruning: same answer, a fraction of the comparisons
+    c3 = umi.Context(0)
+    c3.set_option("prune", 1)
+    try:
+        kept3, root3, st3 = c3.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    finally:
+        c3.close()
+    assert (kept3 == kept).all() and (root3 == root).all()
+    assert st3["n_pairs_evaluated"] < stats["n_pairs_evaluated"] // 3
 
 
 def test_config3_many_small_buckets(ctx):

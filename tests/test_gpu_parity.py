@@ -8,14 +8,18 @@ from helpers import canonical, random_bucket
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["default", "nofuse"])
+@pytest.fixture(scope="module", params=["default", "nofuse", "prune"])
 def ctx(request):
     """default: fused one-wave kernel for buckets <= 128, popcount chunks to 1024, bit-sliced
-    tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list."""
+    tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list.
+    prune: every bucket > 128 through key-sorted bit-sliced tiles with range pruning."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
     if request.param == "nofuse":
         c.set_option("fused_max", 0)
+    if request.param == "prune":
+        c.set_option("prune", 1)
+        c.set_option("small_max", 128)
     yield c
     c.close()
 
@@ -181,6 +185,10 @@ def test_bitsliced_rows_beyond_one_tile_and_column_chunks():
     try:
         st = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
         assert st["n_pair_launches"] >= 1
+        c.set_option("prune", 1)
+        st2 = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
+        assert st2["n_pairs_evaluated"] <= st["n_pairs_evaluated"]  # tile tasks may be skipped
+        assert st2["n_edges"] == st["n_edges"]
     finally:
         c.close()
 

@@ -76,9 +76,15 @@ struct Plan {
     // bit-sliced tasks: [0] 64-thread tiles, [1] 256-thread tiles (diagonal tiles first)
     std::vector<BsTask> bs_tasks[2];
     std::vector<PlaneTask> plane_tasks;
+    struct BsBucket {
+        uint64_t s, e, plane_off;
+        uint32_t ngroups;
+        bool wide;
+    };
+    std::vector<BsBucket> bs_buckets;
     uint64_t n_fused = 0; // buckets left to the fused one-wave kernel
     uint64_t plane_words = 0;
-    uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
+    uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0, n_tasks_pruned = 0;
     size_t n_bs() const
     {
         return bs_tasks[0].size() + bs_tasks[1].size();
@@ -104,6 +110,8 @@ struct umi_ctx {
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
+    DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
+    bool prune = false;
     Plan plan;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
@@ -114,18 +122,80 @@ struct umi_ctx {
 
 namespace {
 
+// Lower bound on the distance between any key of sorted range A and any key of sorted range
+// B, from the bases the ranges' own bounds already fix: all keys between lo and hi share
+// every base above the highest bit in which lo and hi differ.  bpb = bits per base in the
+// filter key (2 for 32-bit keys, 3 for 64-bit ones).
+int shared_top_bases(uint64_t lo, uint64_t hi, int umi_len, int bpb)
+{
+    const uint64_t x = lo ^ hi;
+    if (!x) return umi_len;
+    const int hb = 63 - __builtin_clzll(x);
+    return std::max(0, umi_len - 1 - hb / bpb);
+}
+int range_distance_bound(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, int umi_len,
+                         int bpb)
+{
+    const int t = std::min(shared_top_bases(a_lo, a_hi, umi_len, bpb),
+                           shared_top_bases(b_lo, b_hi, umi_len, bpb));
+    int mism = 0;
+    const uint64_t mask = (1ull << bpb) - 1;
+    for (int i = umi_len - t; i < umi_len; i++)
+        mism += ((a_lo >> (bpb * i)) & mask) != ((b_lo >> (bpb * i)) & mask);
+    return mism;
+}
+
+// Tile tasks of the bit-sliced kernel for every large bucket.  samples (prune mode, else
+// null): per bucket the sorted filter keys at positions s, s+128, ..., and e-1.
+void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
+                  const std::vector<std::vector<uint64_t>> *samples, bool key32)
+{
+    const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
+    const int bpb = key32 ? 2 : 3;
+    for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
+        const Plan::BsBucket &bb = pl.bs_buckets[bi];
+        const uint64_t s = bb.s, e = bb.e;
+        const uint32_t tile_groups = (bb.wide ? 256u : 64u) * gpl;
+        const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
+        auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
+        auto key_hi = [&](uint64_t end) { // an upper bound of the last key of [.., end)
+            if (end >= e) return smp->back();
+            const uint64_t idx = (end - s + BS_COL_TILE - 1) / BS_COL_TILE;
+            return idx < smp->size() ? (*smp)[idx] : smp->back();
+        };
+        for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
+            const uint64_t r_lo = s + (uint64_t)g0 * 32;
+            const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
+            for (uint64_t c0 = r_lo; c0 < e; c0 += col_chunk) {
+                const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
+                const bool diag = c0 < r_hi;
+                if (smp && !diag &&
+                    range_distance_bound(key_lo(r_lo), key_hi(r_hi), key_lo(c0), key_hi(c1), umi_len,
+                                         bpb) > k) {
+                    pl.n_tasks_pruned++;
+                    continue; // no pair of this tile can be within k
+                }
+                BsTask t{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
+                         (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
+                pl.bs_tasks[bb.wide ? 1 : 0].push_back(t);
+                pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
+            }
+        }
+    }
+}
+
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, uint32_t col_chunk, uint32_t fused_max, Plan &pl)
+                int umi_len, uint32_t fused_max, bool narrow_only, Plan &pl)
 {
     pl.n_fused = 0;
     pl.small_tasks.clear();
     pl.big_tasks.clear();
     for (auto &v : pl.bs_tasks) v.clear();
     pl.plane_tasks.clear();
+    pl.bs_buckets.clear();
     pl.plane_words = 0;
-    pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = 0;
+    pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = pl.n_tasks_pruned = 0;
     const uint32_t np = 2 * (uint32_t)bs_padded_len(umi_len);
-    const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
     for (uint64_t b = 0; b < n_buckets; b++) {
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
         const uint64_t n = e - s;
@@ -142,23 +212,13 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             }
         } else if (use_bs) {
             const uint32_t ngroups = (uint32_t)((n + 31) / 32);
-            const bool wide = n >= (uint64_t)BS_WIDE_MIN;
-            const uint32_t tile_groups = (wide ? 256u : 64u) * gpl;
+            // prune mode wants small row tiles: the shorter the key range of a tile, the more
+            // leading bases it fixes and the more column chunks it can rule out
+            const bool wide = !narrow_only && n >= (uint64_t)BS_WIDE_MIN;
             for (uint32_t g = 0; g < ngroups; g += 2)
                 pl.plane_tasks.push_back(
                     {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
-            for (uint32_t g0 = 0; g0 < ngroups; g0 += tile_groups) {
-                const uint64_t r_lo = s + (uint64_t)g0 * 32;
-                const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
-                for (uint64_t c0 = r_lo; c0 < e; c0 += col_chunk) {
-                    const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
-                    const bool diag = c0 < r_hi;
-                    BsTask t{(uint32_t)s, (uint32_t)e, g0, ngroups, pl.plane_words,
-                             (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
-                    pl.bs_tasks[wide ? 1 : 0].push_back(t);
-                    pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
-                }
-            }
+            pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide});
             pl.plane_words += (uint64_t)np * ngroups;
         } else {
             for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
@@ -226,10 +286,11 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         (mode == MODE_NEIGHBOURS || !need_pairs) ? 0u : std::min<uint32_t>(ctx->fused_max, FUSED_MAX);
     Plan &pl = ctx->plan; // vectors keep their capacity between calls
     build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
-               ctx->bs_col_chunk, fused_max, pl);
+               fused_max, ctx->prune, pl);
+    const bool prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
+    if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
     st.max_bucket = pl.max_bucket;
     st.n_pairs = pl.n_pairs;
-    if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
 
     int rc;
     if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
@@ -238,10 +299,10 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
         (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
         return rc;
-    const size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
+    // (bit-sliced tasks may still be generated below, in prune mode)
+    size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + (prune ? 1 : 0);
     if ((rc = ctx->tasks.reserve(
              std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) * sizeof(PairTask))) ||
-        (rc = ctx->bs_tasks.reserve(std::max<size_t>(1, pl.n_bs()) * sizeof(BsTask))) ||
         (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
                                        sizeof(PlaneTask))) ||
         (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
@@ -261,20 +322,7 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
         HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
     }
-    if (pl.n_bs()) {
-        BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
-        size_t off = 0;
-        for (auto &v : pl.bs_tasks) {
-            if (!v.empty())
-                HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
-                                       hipMemcpyHostToDevice, s));
-            off += v.size();
-        }
-        HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
-                               pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice,
-                               s));
-    }
-    if (n_tasks) {
+    if (!pl.small_tasks.empty() || !pl.big_tasks.empty()) {
         PairTask *d_tasks = ctx->tasks.as<PairTask>();
         if (!pl.small_tasks.empty())
             HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
@@ -288,10 +336,66 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
     HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
                         percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
                         ctx->label.as<uint32_t>(), d_cnt, s));
-    if (need_pairs && pl.n_bs())
-        HIP_TRY(launch_build_planes(ctx->fkey.p, key32, ctx->plane_tasks.as<PlaneTask>(),
+    const void *bs_fkey = ctx->fkey.p; // filter keys the bit-sliced tiles are cut from
+    const uint32_t *bs_perm = nullptr;
+    if (prune) {
+        // sort every large bucket by filter key, read back the keys at the tile boundaries,
+        // and keep only the tile tasks whose key ranges can still hold a pair within k
+        const size_t ksz = key32 ? 4 : 8;
+        size_t tmp_bytes = 0, n_pos = 0;
+        for (auto &bb : pl.bs_buckets) {
+            tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
+            n_pos += (bb.e - bb.s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
+        }
+        if ((rc = ctx->fkey_sorted.reserve((size_t)n * ksz)) || (rc = ctx->perm.reserve((size_t)n * 4)) ||
+            (rc = ctx->iota.reserve((size_t)n * 4)) || (rc = ctx->sort_tmp.reserve(tmp_bytes)) ||
+            (rc = ctx->sample_pos.reserve(n_pos * 4)) || (rc = ctx->sample_out.reserve(n_pos * 8)))
+            return rc;
+        std::vector<uint32_t> pos;
+        pos.reserve(n_pos);
+        for (auto &bb : pl.bs_buckets) {
+            HIP_TRY(sort_bucket(ctx->fkey.p, key32, (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+                                ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
+                                ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
+            for (uint64_t q = bb.s; q < bb.e; q += BS_COL_TILE) pos.push_back((uint32_t)q);
+            pos.push_back((uint32_t)(bb.e - 1));
+        }
+        std::vector<uint64_t> flat(pos.size());
+        HIP_TRY(hipMemcpyAsync(ctx->sample_pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(gather_keys(ctx->fkey_sorted.p, key32, ctx->sample_pos.as<uint32_t>(),
+                            (uint32_t)pos.size(), ctx->sample_out.as<uint64_t>(), s));
+        HIP_TRY(hipMemcpyAsync(flat.data(), ctx->sample_out.p, pos.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<std::vector<uint64_t>> samples(pl.bs_buckets.size());
+        size_t o = 0;
+        for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
+            const size_t cnt = (pl.bs_buckets[bi].e - pl.bs_buckets[bi].s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
+            samples[bi].assign(flat.begin() + o, flat.begin() + o + cnt);
+            o += cnt;
+        }
+        gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
+        bs_fkey = ctx->fkey_sorted.p;
+        bs_perm = ctx->perm.as<uint32_t>();
+    }
+    n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
+    if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
+    if (need_pairs && pl.n_bs()) {
+        if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask)))) return rc;
+        BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
+        size_t off = 0;
+        for (auto &v : pl.bs_tasks) {
+            if (!v.empty())
+                HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
+                                       hipMemcpyHostToDevice, s));
+            off += v.size();
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
+                               pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice,
+                               s));
+        HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
                                     (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
                                     umi_len, s));
+    }
     if (prof) HIP_TRY(hipEventRecord(ev[1], s));
 
     // whole small buckets, all-pairs and collapse fused, straight to label[] / status[]
@@ -325,15 +429,19 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             a.mode = mode;
             a.adj_max_freq = adj_max_freq;
             a.planes = ctx->planes.as<uint32_t>();
+            a.perm = nullptr;
             a.bs_tasks = ctx->bs_tasks.as<BsTask>();
             a.tasks = ctx->tasks.as<PairTask>();
             // largest work first: wide bit-sliced tiles, narrow ones, then the popcount kernels
             {
-                PairArgs b = a;
-                b.bs_tasks = a.bs_tasks + pl.bs_tasks[0].size();
-                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
+                PairArgs b = a; // bit-sliced tiles: key-sorted arrays in prune mode
+                b.fkey = bs_fkey;
+                b.perm = bs_perm;
+                PairArgs w = b;
+                w.bs_tasks = b.bs_tasks + pl.bs_tasks[0].size();
+                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
                                         ctx->bs_unit, s));
-                HIP_TRY(launch_bs_pairs(a, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
+                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
                                         ctx->bs_unit, s));
             }
             a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
@@ -498,7 +606,8 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes,
+    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->fkey_sorted, &ctx->perm,
+                      &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
@@ -520,6 +629,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+    } else if (!strcmp(name, "prune")) {
+        ctx->prune = value != 0;
     } else if (!strcmp(name, "bs_unit")) {
         if (value < 1 || value > 3) return fail(UMI_ERR_ARG, "bs_unit must be 1, 2 or 3");
         ctx->bs_unit = (int)value;
@@ -527,8 +638,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
         ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);
     } else if (!strcmp(name, "bs_col_chunk")) {
-        if (value < BS_COL_TILE || value > (1 << 24))
-            return fail(UMI_ERR_ARG, "bs_col_chunk outside %d..%d", BS_COL_TILE, 1 << 24);
+        if (value < BS_COL_TILE || value > (1 << 24) || value % BS_COL_TILE)
+            return fail(UMI_ERR_ARG, "bs_col_chunk must be a multiple of %d in %d..%d", BS_COL_TILE,
+                        BS_COL_TILE, 1 << 24);
         ctx->bs_col_chunk = (uint32_t)value;
     } else if (!strcmp(name, "bitslice")) {
         ctx->use_bitslice = value != 0;

@@ -66,6 +66,7 @@ struct PairArgs {
     const PairTask *tasks;
     const BsTask *bs_tasks;
     const uint32_t *planes;
+    const uint32_t *perm; // prune mode: sorted position -> original entry index (else null)
     uint2 *edges;
     uint8_t *edge_dist; // MODE_NEIGHBOURS only
     unsigned long long *counters;
@@ -101,10 +102,22 @@ inline int bs_padded_len(int umi_len) { return umi_len <= 8 ? 8 : umi_len <= 12 
 inline int bs_groups_per_lane(int umi_len) { return umi_len <= 16 ? 2 : 1; }
 hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *tasks,
                                uint32_t n_tasks, uint32_t *planes, int umi_len, hipStream_t s);
-// wide: 256-thread blocks (256*G groups per tile), else 64-thread blocks
+// wide: the 4 waves of a block hold different row groups (256*G groups per tile); else they
+// hold the same 64*G groups and split the columns
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, hipStream_t s);
+
+// ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
+size_t sort_temp_bytes(bool key32, uint32_t n);
+// fkey_sorted[start..start+n) = sorted keys, perm[start + i] = original global index of the
+// i-th smallest; iota_tmp is scratch of the same extent
+hipError_t sort_bucket(const void *fkey, bool key32, uint32_t start, uint32_t n, void *fkey_sorted,
+                       uint32_t *perm, uint32_t *iota_tmp, void *tmp, size_t tmp_bytes,
+                       hipStream_t s);
+// out[i] = keys[pos[i]] widened to 64 bits
+hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32_t n, uint64_t *out,
+                       hipStream_t s);
 
 // all-pairs + collapse of whole small buckets (2..fused_max entries), one wave per bucket;
 // walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[])

@@ -131,9 +131,14 @@ __device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
                                          uint8_t *edge_dist, unsigned long long *counters,
                                          EdgeStage *st, uint32_t edge_cap, int k, int mode,
                                          int32_t adj_max_freq, uint32_t row_end, uint32_t col1,
-                                         uint32_t gi, uint32_t gj)
+                                         uint32_t gi, uint32_t gj, const uint32_t *perm)
 {
     if (gi >= row_end || gj >= col1 || gi >= gj) return;
+    if (perm) { // prune mode: the tile lives in key-sorted order; back to entry indices
+        const uint32_t oi = perm[gi], oj = perm[gj];
+        gi = min(oi, oj);
+        gj = max(oi, oj);
+    }
     atomicAdd(&st->candidates, 1u);
     const uint64_t ka = keys[gi], kb = keys[gj];
     const uint64_t na = nmask ? nmask[gi] : 0ull, nb = nmask ? nmask[gj] : 0ull;
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(THREADS) void pair_kernel(PairArgs a)
                             if (popc(rk[r] ^ cols[cb + c]) <= lim)
                                 verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist,
                                             a.counters, &stage, a.edge_cap, a.k, a.mode,
-                                            a.adj_max_freq, row_end, col1, gi, c0 + cb + c);
+                                            a.adj_max_freq, row_end, col1, gi, c0 + cb + c,
+                                            nullptr);
                         }
                     }
                 }
@@ -314,9 +320,14 @@ __global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict
 #define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
 constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
 
-template <typename KeyT, int LP, int G, int K, int THREADS, int GB>
-__global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
+// COLSPLIT = false: the block's 4 waves hold 4 x 64 x G different row groups and all walk
+// every column (tiles of 8192*G rows, for very large buckets).  COLSPLIT = true: the 4 waves
+// hold the SAME 64 x G row groups and take every 4th column of the staged tile, so a bucket of
+// a few thousand entries still fills its lanes while the LDS staging is shared by 4 waves.
+template <typename KeyT, int LP, int G, int K, bool COLSPLIT, int GB>
+__global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
 {
+    constexpr int THREADS = 256;
     constexpr int NP = 2 * LP;
     static_assert(LP % GB == 0 && NP % 4 == 0, "padded base count must be a multiple of the unit");
     __shared__ __attribute__((aligned(16))) uint32_t cmask[BS_COL_TILE * NP];
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
     uint32_t rbase[G]; // bucket-relative index of the group's first row
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const uint32_t grp = group0 + g * THREADS + tid;
+        const uint32_t grp = COLSPLIT ? group0 + g * 64 + (tid & 63) : group0 + g * THREADS + tid;
 #pragma unroll
         for (int b = 0; b < NP; b++) p[g][b] = grp < ngroups ? planes[(uint64_t)b * ngroups + grp] : 0u;
         rbase[g] = grp * 32;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
             cmask[w] = bit_of(fkey[c0 + c], (int)b) ? 0xFFFFFFFFu : 0u;
         }
         __syncthreads();
-        for (uint32_t c = 0; c < nc; c++) {
+        for (uint32_t c = COLSPLIT ? (uint32_t)(tid >> 6) : 0u; c < nc; c += COLSPLIT ? 4u : 1u) {
             uint32_t cm[NP];
 #pragma unroll
             for (int q = 0; q < NP / 4; q++)
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(THREADS) void bs_pair_kernel(PairArgs a)
                         hh &= hh - 1;
                         verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
                                     &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
-                                    bucket_start + rbase[g] + j, c0 + c);
+                                    bucket_start + rbase[g] + j, c0 + c, a.perm);
                     }
                 }
             }
@@ -790,14 +801,14 @@ void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, hipSt
     // superset of distance <= K that verify_pair makes exact), 1 = exact base count,
     // 3 = fewer ops but 7x the false candidates on random 12-mers (k = 1, L' % 3 == 0 only)
     if (unit == 1) {
-        if (wide) bs_pair_kernel<KeyT, LP, G, K, 256, 1><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, LP, G, K, 64, 1><<<n_tasks, 64, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 1><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, true, 1><<<n_tasks, 256, 0, s>>>(a);
     } else if (unit == 3 && LP % 3 == 0 && K == 1) {
-        if (wide) bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, 256, 3><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, 64, 3><<<n_tasks, 64, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, false, 3><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, true, 3><<<n_tasks, 256, 0, s>>>(a);
     } else {
-        if (wide) bs_pair_kernel<KeyT, LP, G, K, 256, 2><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, LP, G, K, 64, 2><<<n_tasks, 64, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 2><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, true, 2><<<n_tasks, 256, 0, s>>>(a);
     }
 }
 template <typename KeyT, int LP, int G>
