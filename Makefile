@@ -6,12 +6,24 @@ CSRC := $(PKG)/csrc
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unused-parameter
 
 LIB := $(PKG)/libumihip.so
-SRCS := $(CSRC)/umihip_kernels.hip $(CSRC)/umihip_sort.hip $(CSRC)/umihip_api.cpp
+OBJDIR := build/obj
+OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_sort.o $(OBJDIR)/umihip_api.o
 HDRS := $(CSRC)/umihip_internal.h include/umihip.h
-
 CLI := $(PKG)/bin/umicollapse
 
 all: $(LIB) oracle cpptest $(CLI)
+
+# one object per translation unit (the rocPRIM sort alone takes ~20 s to compile)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ -x hip $<
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ -x hip $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
 
 $(CLI): $(LIB) $(PKG)/host/umicollapse_main.cpp $(PKG)/host/bam.hpp $(PKG)/host/bgzf.hpp include/umihip.h
 	mkdir -p $(PKG)/bin
@@ -19,9 +31,6 @@ $(CLI): $(LIB) $(PKG)/host/umicollapse_main.cpp $(PKG)/host/bam.hpp $(PKG)/host/
 	    -Wl,-rpath,'$$ORIGIN/..'
 
 cli: $(CLI)
-
-$(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS)
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -256,97 +256,160 @@ int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, i
     return UMI_OK;
 }
 
-// The device pipeline shared by both batched entry points and by umi_data_new.
-// mode MODE_NEIGHBOURS stops after the pair kernels (edges hold the neighbour pairs).
-int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
-                 const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
-                 int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
-                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats)
-{
-    HIP_TRY(hipSetDevice(ctx->device));
-    // Every early return below leaves with the stream drained: work already enqueued reads
-    // caller memory (bucket_off) and workspace buffers the next call may reallocate.
-    struct DrainOnExit {
-        hipStream_t s;
-        bool armed = true;
-        ~DrainOnExit()
-        {
-            if (armed) (void)hipStreamSynchronize(s);
-        }
-    } drain{s};
-    umi_stats st;
-    memset(&st, 0, sizeof(st));
-    st.n_umis = n;
-    st.n_buckets = n_buckets;
-
-    const bool key32 = umi_len <= 16;
-    const bool need_pairs =
-        !(mode == MODE_ADJACENCY && adj_max_freq < 1); // reference adj: only the query goes
-    const uint32_t fused_max =
-        (mode == MODE_NEIGHBOURS || !need_pairs) ? 0u : std::min<uint32_t>(ctx->fused_max, FUSED_MAX);
-    Plan &pl = ctx->plan; // vectors keep their capacity between calls
-    build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K, umi_len,
-               fused_max, ctx->prune, pl);
-    const bool prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
-    if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
-    st.max_bucket = pl.max_bucket;
-    st.n_pairs = pl.n_pairs;
-
-    int rc;
-    if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
-        (rc = ctx->label.reserve((size_t)n * 4)) ||
-        (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
-        (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
-        (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
-        return rc;
-    // (bit-sliced tasks may still be generated below, in prune mode)
-    size_t n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + (prune ? 1 : 0);
-    if ((rc = ctx->tasks.reserve(
-             std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) * sizeof(PairTask))) ||
-        (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
-                                       sizeof(PlaneTask))) ||
-        (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
-        return rc;
-    if (mode == MODE_ADJACENCY && need_pairs)
-        if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
-    const size_t n_fused = pl.n_fused;
-
-    unsigned long long *d_cnt = ctx->counters.as<unsigned long long>();
-    hipEvent_t *ev = ctx->ev;
-    const bool prof = ctx->profile;
-
-    if (prof) HIP_TRY(hipEventRecord(ev[0], s));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
-    HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
-    if (mode == MODE_ADJACENCY && need_pairs) {
-        HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
-        HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
+// The device pipeline shared by both batched entry points and by umi_data_new, as a
+// sequence of stages over one stream.  mode MODE_NEIGHBOURS stops after the pair kernels
+// (the edge list then holds the neighbour pairs).
+class Pipeline {
+  public:
+    Pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask, const int32_t *d_freq,
+             const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len, int k,
+             float percentage, int mode, int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
+             hipStream_t s)
+        : ctx(ctx), d_keys(d_keys), d_nmask(d_nmask), d_freq(d_freq), bucket_off(bucket_off),
+          n_buckets(n_buckets), n(n), umi_len(umi_len), k(k), percentage(percentage), mode(mode),
+          adj_max_freq(adj_max_freq), d_kept(d_kept), d_root(d_root), s(s), pl(ctx->plan),
+          key32(umi_len <= 16),
+          need_pairs(!(mode == MODE_ADJACENCY && adj_max_freq < 1)), // reference adj: only the query goes
+          fused_max((mode == MODE_NEIGHBOURS || !need_pairs)
+                        ? 0u
+                        : std::min<uint32_t>(ctx->fused_max, FUSED_MAX)),
+          prof(ctx->profile)
+    {
+        memset(&st, 0, sizeof(st));
+        st.n_umis = n;
+        st.n_buckets = n_buckets;
     }
-    if (!pl.small_tasks.empty() || !pl.big_tasks.empty()) {
+
+    int run(umi_stats *stats)
+    {
+        HIP_TRY(hipSetDevice(ctx->device));
+        int rc = run_stages();
+        // Leave with the stream drained on every path: enqueued work reads caller memory
+        // (bucket_off) and workspace buffers that the next call may reallocate.
+        if (!drained) (void)hipStreamSynchronize(s);
+        if (rc == UMI_OK && stats) *stats = st;
+        return rc;
+    }
+
+  private:
+    umi_ctx *ctx;
+    const uint64_t *d_keys, *d_nmask;
+    const int32_t *d_freq;
+    const uint64_t *bucket_off;
+    uint64_t n_buckets;
+    uint32_t n;
+    int umi_len, k;
+    float percentage;
+    int mode;
+    int32_t adj_max_freq;
+    uint8_t *d_kept;
+    uint32_t *d_root;
+    hipStream_t s;
+    Plan &pl; // lives in the context: its vectors keep their capacity between calls
+    const bool key32, need_pairs;
+    const uint32_t fused_max;
+    const bool prof;
+    bool prune = false, drained = false;
+    umi_stats st;
+    unsigned long long *d_cnt = nullptr;
+    size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
+    uint64_t n_edges = 0;
+    uint32_t cap_used = 0;
+    const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
+    const uint32_t *bs_perm = nullptr;
+
+    int run_stages()
+    {
+        int rc;
+        if ((rc = plan_and_reserve())) return rc;
+        if ((rc = upload_and_prep())) return rc;
+        if (prune && (rc = prune_stage())) return rc;
+        if ((rc = upload_bitsliced())) return rc;
+        if ((rc = pair_stage())) return rc;
+        if (mode == MODE_NEIGHBOURS) return finish_neighbours();
+        if (mode == MODE_DIRECTIONAL || !need_pairs)
+            rc = collapse_directional();
+        else
+            rc = collapse_adjacency();
+        if (rc) return rc;
+        return finish();
+    }
+
+    int sync_counters()
+    {
+        HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ctx->h_counters[CNT_ERROR])
+            return fail(UMI_ERR_ORDER,
+                        "%llu entries break the input contract (freq < 1 or not in "
+                        "freq-descending rank order inside a bucket)",
+                        ctx->h_counters[CNT_ERROR]);
+        return UMI_OK;
+    }
+
+    // host planning + workspace
+    int plan_and_reserve()
+    {
+        build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
+                   umi_len, fused_max, ctx->prune, pl);
+        prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
+        if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
+        st.max_bucket = pl.max_bucket;
+        st.n_pairs = pl.n_pairs;
+        int rc;
+        if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
+            (rc = ctx->label.reserve((size_t)n * 4)) ||
+            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
+            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
+            (rc = ctx->boff.reserve((n_buckets + 1) * 8)) ||
+            (rc = ctx->tasks.reserve(std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) *
+                                     sizeof(PairTask))) ||
+            (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
+                                           sizeof(PlaneTask))) ||
+            (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
+            return rc;
+        if (mode == MODE_ADJACENCY && need_pairs)
+            if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
+        d_cnt = ctx->counters.as<unsigned long long>();
+        bs_fkey = ctx->fkey.p;
+        return UMI_OK;
+    }
+
+    // counters, bucket table, popcount-kernel tasks; filter keys / thresholds / labels
+    int upload_and_prep()
+    {
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+        if (mode == MODE_ADJACENCY && need_pairs) {
+            HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
+            HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
+        }
         PairTask *d_tasks = ctx->tasks.as<PairTask>();
         if (!pl.small_tasks.empty())
             HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
-                                   pl.small_tasks.size() * sizeof(PairTask),
-                                   hipMemcpyHostToDevice, s));
+                                   pl.small_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
         if (!pl.big_tasks.empty())
             HIP_TRY(hipMemcpyAsync(d_tasks + pl.small_tasks.size(), pl.big_tasks.data(),
-                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice,
-                                   s));
+                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
+                            percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
+                            ctx->label.as<uint32_t>(), d_cnt, s));
+        return UMI_OK;
     }
-    HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
-                        percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
-                        ctx->label.as<uint32_t>(), d_cnt, s));
-    const void *bs_fkey = ctx->fkey.p; // filter keys the bit-sliced tiles are cut from
-    const uint32_t *bs_perm = nullptr;
-    if (prune) {
-        // sort every large bucket by filter key, read back the keys at the tile boundaries,
-        // and keep only the tile tasks whose key ranges can still hold a pair within k
+
+    // optional: sort every large bucket by filter key, read back the keys at the tile
+    // boundaries, keep only the tile tasks whose key ranges can still hold a pair within k
+    int prune_stage()
+    {
         const size_t ksz = key32 ? 4 : 8;
         size_t tmp_bytes = 0, n_pos = 0;
         for (auto &bb : pl.bs_buckets) {
             tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
             n_pos += (bb.e - bb.s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
         }
+        int rc;
         if ((rc = ctx->fkey_sorted.reserve((size_t)n * ksz)) || (rc = ctx->perm.reserve((size_t)n * 4)) ||
             (rc = ctx->iota.reserve((size_t)n * 4)) || (rc = ctx->sort_tmp.reserve(tmp_bytes)) ||
             (rc = ctx->sample_pos.reserve(n_pos * 4)) || (rc = ctx->sample_out.reserve(n_pos * 8)))
@@ -369,129 +432,129 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         std::vector<std::vector<uint64_t>> samples(pl.bs_buckets.size());
         size_t o = 0;
         for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
-            const size_t cnt = (pl.bs_buckets[bi].e - pl.bs_buckets[bi].s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
+            const size_t cnt =
+                (pl.bs_buckets[bi].e - pl.bs_buckets[bi].s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
             samples[bi].assign(flat.begin() + o, flat.begin() + o + cnt);
             o += cnt;
         }
         gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
+        return UMI_OK;
     }
-    n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
-    if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
-    if (need_pairs && pl.n_bs()) {
-        if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask)))) return rc;
-        BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
-        size_t off = 0;
-        for (auto &v : pl.bs_tasks) {
-            if (!v.empty())
-                HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
-                                       hipMemcpyHostToDevice, s));
-            off += v.size();
-        }
-        HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
-                               pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice,
-                               s));
-        HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
-                                    (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
-                                    umi_len, s));
-    }
-    if (prof) HIP_TRY(hipEventRecord(ev[1], s));
 
-    // whole small buckets, all-pairs and collapse fused, straight to label[] / status[]
-    if (n_fused) {
-        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
-                                     ctx->boff.as<uint64_t>(), (uint32_t)n_buckets, fused_max,
-                                     ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
-                                     adj_max_freq, s));
-        st.n_pair_launches += 1;
+    // bit-sliced tile tasks + bit planes of the large buckets
+    int upload_bitsliced()
+    {
+        n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
+        if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
+        if (need_pairs && pl.n_bs()) {
+            int rc;
+            if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask)))) return rc;
+            BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
+            size_t off = 0;
+            for (auto &v : pl.bs_tasks) {
+                if (!v.empty())
+                    HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
+                                           hipMemcpyHostToDevice, s));
+                off += v.size();
+            }
+            HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
+                                   pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice, s));
+            HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
+                                        (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
+                                        umi_len, s));
+        }
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[1], s));
+        return UMI_OK;
     }
-    uint64_t n_edges = 0;
-    uint32_t cap_used = 0;
-    if (need_pairs && n_tasks) {
+
+    // all-pairs: fused small buckets straight to label[]/status[]; tile kernels to the edge list
+    // (redone once with a larger list if it overflowed: the exact count is known by then)
+    int pair_stage()
+    {
+        if (pl.n_fused) {
+            HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
+                                         ctx->boff.as<uint64_t>(), (uint32_t)n_buckets, fused_max,
+                                         ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
+                                         adj_max_freq, s));
+            st.n_pair_launches += 1;
+        }
+        if (!(need_pairs && n_tasks)) {
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
+            return UMI_OK;
+        }
+        int rc;
         uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
         for (int attempt = 0;; attempt++) {
-            if (cap > 0xFFFFFFF0ull) return fail(UMI_ERR_NOMEM, "edge list too large");
+            if (cap > 0x7FFFFFF0ull) return fail(UMI_ERR_NOMEM, "edge list too large");
             if ((rc = ctx->edges.reserve(cap * sizeof(uint2)))) return rc;
             if (mode == MODE_NEIGHBOURS && (rc = ctx->edge_dist.reserve(cap))) return rc;
+            cap_used = (uint32_t)cap;
             PairArgs a;
             a.keys = d_keys;
             a.nmask = d_nmask;
             a.freq = d_freq;
             a.thr = ctx->thr.as<int32_t>();
             a.fkey = ctx->fkey.p;
+            a.tasks = ctx->tasks.as<PairTask>();
+            a.bs_tasks = ctx->bs_tasks.as<BsTask>();
+            a.planes = ctx->planes.as<uint32_t>();
+            a.perm = nullptr;
             a.edges = ctx->edges.as<uint2>();
             a.edge_dist = ctx->edge_dist.as<uint8_t>();
             a.counters = d_cnt;
-            a.edge_cap = (uint32_t)cap;
-            cap_used = (uint32_t)cap;
+            a.edge_cap = cap_used;
             a.k = k;
             a.mode = mode;
             a.adj_max_freq = adj_max_freq;
-            a.planes = ctx->planes.as<uint32_t>();
-            a.perm = nullptr;
-            a.bs_tasks = ctx->bs_tasks.as<BsTask>();
-            a.tasks = ctx->tasks.as<PairTask>();
-            // largest work first: wide bit-sliced tiles, narrow ones, then the popcount kernels
-            {
-                PairArgs b = a; // bit-sliced tiles: key-sorted arrays in prune mode
-                b.fkey = bs_fkey;
-                b.perm = bs_perm;
-                PairArgs w = b;
-                w.bs_tasks = b.bs_tasks + pl.bs_tasks[0].size();
-                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
-                                        ctx->bs_unit, s));
-                HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
-                                        ctx->bs_unit, s));
-            }
-            a.tasks = ctx->tasks.as<PairTask>() + pl.small_tasks.size();
-            HIP_TRY(launch_pairs(a, (uint32_t)pl.big_tasks.size(), true, key32, s));
-            a.tasks = ctx->tasks.as<PairTask>();
+            // largest work first: wide bit-sliced tiles, column-split ones, then the popcount kernels
+            PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
+            b.fkey = bs_fkey;
+            b.perm = bs_perm;
+            PairArgs w = b;
+            w.bs_tasks = b.bs_tasks + pl.bs_tasks[0].size();
+            HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
+                                    ctx->bs_unit, s));
+            HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
+                                    ctx->bs_unit, s));
+            PairArgs big = a;
+            big.tasks = a.tasks + pl.small_tasks.size();
+            HIP_TRY(launch_pairs(big, (uint32_t)pl.big_tasks.size(), true, key32, s));
             HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
             for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
             st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
-            if (prof) HIP_TRY(hipEventRecord(ev[2], s));
-            HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
-                                   hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (ctx->h_counters[CNT_ERROR])
-                return fail(UMI_ERR_ORDER,
-                            "%llu entries break the input contract (freq < 1 or not in "
-                            "freq-descending rank order inside a bucket)",
-                            ctx->h_counters[CNT_ERROR]);
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
+            if ((rc = sync_counters())) return rc;
             n_edges = ctx->h_counters[CNT_EDGES];
             st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
             if (n_edges <= cap) break;
             if (attempt >= 2) return fail(UMI_ERR_HIP, "edge list overflow persists");
-            // overflow: the exact count is known now; redo the pair pass with room for it
             cap = n_edges + n_edges / 16 + 1024;
             ctx->edge_capacity = cap;
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
         }
-    } else if (prof) {
-        HIP_TRY(hipEventRecord(ev[2], s));
-    }
-    st.n_edges = n_edges;
-
-    if (mode == MODE_NEIGHBOURS) {
-        if (!need_pairs || !n_tasks) {
-            HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
-                                   hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (ctx->h_counters[CNT_ERROR])
-                return fail(UMI_ERR_ORDER, "freq < 1 in the umi_freq map");
-        }
-        drain.armed = false; // synchronised above
-        if (stats) *stats = st;
+        st.n_edges = n_edges;
         return UMI_OK;
     }
 
-    // ---- collapse
-    if (mode == MODE_DIRECTIONAL || !need_pairs) {
+    int finish_neighbours()
+    {
+        if (!(need_pairs && n_tasks)) { // pair_stage did not read the counters back
+            int rc = sync_counters();
+            if (rc) return rc;
+        }
+        drained = true;
+        return UMI_OK;
+    }
+
+    // min-rank label propagation to the fixed point: rounds are enqueued in growing batches,
+    // each round skips itself on the device once the previous one changed nothing
+    int collapse_directional()
+    {
         if (n_edges) {
             uint32_t *d_changed = ctx->changed.as<uint32_t>();
-            int rounds = 0;
-            int batch = 4;
+            int rounds = 0, batch = 4;
             for (;;) {
                 HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
                 for (int r = 0; r < batch; r++)
@@ -502,12 +565,9 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                                        hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 bool done = false;
-                for (int r = 0; r < batch; r++) {
+                for (int r = 0; r < batch && !done; r++) {
                     rounds++;
-                    if (ctx->h_changed[r] == 0) {
-                        done = true;
-                        break;
-                    }
+                    done = ctx->h_changed[r] == 0;
                 }
                 if (done) break;
                 if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
@@ -515,17 +575,21 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             }
             st.n_rounds = (uint32_t)rounds;
         }
-        if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
         HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
-    } else {
-        // adjacency with max_freq >= 1
+        return UMI_OK;
+    }
+
+    // adjacency with max_freq >= 1: greedy root loop, one decision level per iteration
+    int collapse_adjacency()
+    {
         uint8_t *d_status = ctx->status.as<uint8_t>();
         uint8_t *d_blocked = ctx->blocked.as<uint8_t>();
         int iters = 0;
         for (;;) {
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UNKNOWN], 0, sizeof(unsigned long long), s));
-            HIP_TRY(launch_adj_iter(ctx->edges.as<uint2>(), d_cnt, cap_used, d_status, d_blocked, ctx->label.as<uint32_t>(), n, d_cnt,
-                                    (uint32_t)n_edges, s));
+            HIP_TRY(launch_adj_iter(ctx->edges.as<uint2>(), d_cnt, cap_used, d_status, d_blocked,
+                                    ctx->label.as<uint32_t>(), n, d_cnt, (uint32_t)n_edges, s));
             HIP_TRY(hipMemcpyAsync(&ctx->h_counters[CNT_UNKNOWN], &d_cnt[CNT_UNKNOWN],
                                    sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -534,30 +598,38 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
             if (iters > MAX_ROUNDS) return fail(UMI_ERR_HIP, "adjacency collapse diverged");
         }
         st.n_rounds = (uint32_t)iters;
-        if (prof) HIP_TRY(hipEventRecord(ev[3], s));
-        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt,
-                                    s));
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
+        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+        return UMI_OK;
     }
-    if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-    HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (ctx->h_counters[CNT_ERROR])
-        return fail(UMI_ERR_ORDER,
-                    "%llu entries break the input contract (freq < 1 or not in freq-descending "
-                    "rank order inside a bucket)",
-                    ctx->h_counters[CNT_ERROR]);
-    st.n_kept = ctx->h_counters[CNT_KEPT];
-    if (prof) {
-        HIP_TRY(hipEventElapsedTime(&st.ms_prep, ev[0], ev[1]));
-        HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ev[1], ev[2]));
-        HIP_TRY(hipEventElapsedTime(&st.ms_collapse, ev[2], ev[3]));
-        HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
-        HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
+
+    int finish()
+    {
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
+        int rc = sync_counters();
+        if (rc) return rc;
+        drained = true;
+        st.n_kept = ctx->h_counters[CNT_KEPT];
+        if (prof) {
+            hipEvent_t *ev = ctx->ev;
+            HIP_TRY(hipEventElapsedTime(&st.ms_prep, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ev[1], ev[2]));
+            HIP_TRY(hipEventElapsedTime(&st.ms_collapse, ev[2], ev[3]));
+            HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
+            HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
+        }
+        return UMI_OK;
     }
-    drain.armed = false; // synchronised above
-    if (stats) *stats = st;
-    return UMI_OK;
+};
+
+int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                 const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
+                 int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
+                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats)
+{
+    return Pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, n, umi_len, k, percentage,
+                    mode, adj_max_freq, d_kept, d_root, s)
+        .run(stats);
 }
 
 } // namespace
