@@ -52,12 +52,14 @@ def read_staging(path):
     return dict(keys=keys, nmask=nmask, freq=freq, rep=rep, bucket_off=off, umi_len=umi_len)
 
 
-@pytest.mark.parametrize("merge", ["any", "avgqual", "mapqual"])
-def test_staging_matches_reference_restatement(tmp_path, merge):
+@pytest.mark.parametrize("merge,threads", [("any", 1), ("avgqual", 1), ("mapqual", 1),
+                                           ("avgqual", 7), ("mapqual", 16)])
+def test_staging_matches_reference_restatement(tmp_path, merge, threads):
     header, recs = bamio.synthetic_bam(2, 120, 40, umi_len=12, err=0.03)
     src, dump = str(tmp_path / "in.bam"), str(tmp_path / "stage.bin")
     write_bam(src, header, recs)
-    r = run(["-i", src, "-o", str(tmp_path / "unused.bam"), "--merge", merge, "--dump-staging", dump])
+    r = run(["-i", src, "-o", str(tmp_path / "unused.bam"), "--merge", merge, "--dump-staging", dump,
+             "--num-threads", str(threads)])
     assert r.returncode == 0, r.stderr
     got = read_staging(dump)
     exp, _ = bamio.stage_like_reference(recs, merge=merge)

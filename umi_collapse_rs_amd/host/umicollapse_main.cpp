@@ -6,6 +6,7 @@
 // freq ties follow first appearance in the input (canonical determinisation).
 // Not implemented, as in / beyond the reference: --mode fastq and --tag (unfinished in the
 // reference: main.rs:49-50, deduplicate_sam.rs:236-239), --paired (N4), --two-pass, --algo cc.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -162,78 +163,140 @@ int main(int argc, char **argv)
         in.parse();
         const double t_read = now_s();
 
-        // ---- staging: deduplicate_sam.rs:93-177
-        size_t total_read_count = 0, unmapped = 0;
+        // ---- staging: deduplicate_sam.rs:93-177, in three passes so that --num-threads helps:
+        //  A (parallel over records)  alignment key, UMI key, merge score of every read
+        //  B (parallel over shards of the alignment-key hash; every shard walks the reads in
+        //     file order)              per-bucket UMI maps with the reference's merge rule
+        //  C (sequential)             buckets in order of first appearance, entries in rank order
+        const uint32_t n_rec = (uint32_t)in.records.size();
+        const unsigned T = std::max(1u, args.num_threads);
         size_t umi_length = args.umi_length;
+        if (umi_length == 0 && !args.passthrough) // autodetect on the first mapped read (:154-156)
+            for (uint32_t ri = 0; ri < n_rec; ri++)
+                if (!in.records[ri].is_unmapped()) {
+                    umi_length = detect_umi_length(in.records[ri].qname(), in.records[ri].qname_len(), args.umi_sep);
+                    break;
+                }
+        struct ReadInfo {
+            uint64_t coord, ref_strand, key, nmask;
+            int32_t score;
+            uint8_t state; // 0 mapped, 1 unmapped, 2 error
+        };
+        std::vector<ReadInfo> info(n_rec);
+        std::vector<std::string> errors(T);
+        std::vector<uint32_t> first_error(T, UINT32_MAX);
+        const uint32_t chunk = (n_rec + T - 1) / T;
+        umi::bgzf::parallel_for(T, T, [&](size_t t) {
+            const uint32_t lo = (uint32_t)t * chunk, hi = std::min(n_rec, lo + chunk);
+            for (uint32_t ri = lo; ri < hi; ri++) {
+                const umi::bam::Record &r = in.records[ri];
+                ReadInfo &ii = info[ri];
+                if (r.is_unmapped()) { ii.state = 1; continue; } // :102-108
+                ii.state = 0;
+                if (args.passthrough) continue;
+                // Alignment{strand, coord, ref} (:141-145); equality on tid == equality on the name
+                ii.coord = (uint64_t)r.unclipped_pos();
+                ii.ref_strand = ((uint64_t)(uint32_t)r.tid() << 1) | (r.is_reverse() ? 1u : 0u);
+                const uint8_t *q = r.qname();
+                const size_t qn = r.qname_len();
+                const uint8_t *sp = (const uint8_t *)std::memchr(q, args.umi_sep, qn); // read.rs:100
+                const char *err = nullptr;
+                const size_t at = sp ? (size_t)(sp - q) + 1 : 0;
+                if (!sp) err = "failed to get the umi";
+                else if (umi_length == 0) err = "Empty UMI sequence extracted";
+                else if (at + umi_length > qn) err = "UMI runs past the end of the read name";
+                else if (umi_encode_umis(q + at, 1, (int)umi_length, &ii.key, &ii.nmask) != UMI_OK) err = umi_last_error();
+                if (err) {
+                    ii.state = 2;
+                    if (first_error[t] == UINT32_MAX) { first_error[t] = ri; errors[t] = err; }
+                    continue;
+                }
+                ii.score = merge == 2 ? (int32_t)r.mapq() : r.avg_qual();
+            }
+        });
+        for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
+            if (first_error[t] != UINT32_MAX) die(errors[t]);
+
+        size_t total_read_count = n_rec, unmapped = 0;
         std::vector<uint32_t> out_records; // records written before dedup (--keep-unmapped, :104-106)
-        std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> bucket_of; // Align -> bucket
-        std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // per bucket: key -> entry
-        std::vector<std::vector<uint32_t>> bucket_entries;
-        std::vector<Entry> entries;
-        std::vector<uint8_t> umi_buf;
-        for (uint32_t ri = 0; ri < in.records.size(); ri++) {
-            const umi::bam::Record &r = in.records[ri];
-            total_read_count++;
-            if (r.is_unmapped()) { // :102-108
+        for (uint32_t ri = 0; ri < n_rec; ri++) {
+            if (info[ri].state == 1) {
                 unmapped++;
                 if (args.keep_unmapped || args.passthrough) out_records.push_back(ri);
-                continue;
-            }
-            if (args.passthrough) { out_records.push_back(ri); continue; }
-            // Alignment{strand, coord, ref} (:141-145); equality on tid == equality on the name
-            const int64_t coord = r.unclipped_pos();
-            const std::pair<uint64_t, uint64_t> akey((uint64_t)coord,
-                                                     ((uint64_t)(uint32_t)r.tid() << 1) | (r.is_reverse() ? 1u : 0u));
-            auto it = bucket_of.find(akey);
-            uint32_t b;
-            if (it == bucket_of.end()) {
-                b = (uint32_t)bucket_entries.size();
-                bucket_of.emplace(akey, b);
-                bucket_entries.emplace_back();
-                umi_index.emplace_back();
-            } else {
-                b = it->second;
-            }
-            const uint8_t *q = r.qname();
-            const size_t qn = r.qname_len();
-            if (umi_length == 0) umi_length = detect_umi_length(q, qn, args.umi_sep); // :154-156
-            const uint8_t *sp = (const uint8_t *)std::memchr(q, args.umi_sep, qn);    // read.rs:100
-            if (!sp) die("failed to get the umi");
-            const size_t at = (size_t)(sp - q) + 1;
-            if (at + umi_length > qn) die("UMI runs past the end of the read name");
-            if (umi_length == 0) die("Empty UMI sequence extracted");
-            uint64_t key = 0, nmask = 0;
-            if (umi_encode_umis(q + at, 1, (int)umi_length, &key, &nmask) != UMI_OK) die(umi_last_error());
-            const int32_t score = merge == 2 ? (int32_t)r.mapq() : r.avg_qual();
-            auto &idx = umi_index[b];
-            auto e = idx.find(key);
-            if (e == idx.end()) { // Vacant :161-163
-                idx.emplace(key, (uint32_t)entries.size());
-                bucket_entries[b].push_back((uint32_t)entries.size());
-                entries.push_back({key, nmask, 1, score, ri, b});
-            } else { // Occupied :164-175
-                Entry &en = entries[e->second];
-                const bool keep_existing = merge == 0 ? true : en.score >= score; // merge/mod.rs:21,35,49
-                en.freq += 1;
-                if (!keep_existing) { en.rep = ri; en.score = score; }
+            } else if (args.passthrough) {
+                out_records.push_back(ri);
             }
         }
+
+        struct Shard {
+            std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> bucket_of; // Align -> local bucket
+            std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // key -> local entry
+            std::vector<std::vector<uint32_t>> bucket_entries;
+            std::vector<uint32_t> bucket_first; // first read of the bucket
+            std::vector<Entry> entries;
+        };
+        std::vector<Shard> shards(args.passthrough ? 0 : T);
+        KeyHash hasher;
+        umi::bgzf::parallel_for(shards.size(), T, [&](size_t t) {
+            Shard &sh = shards[t];
+            for (uint32_t ri = 0; ri < n_rec; ri++) {
+                const ReadInfo &ii = info[ri];
+                if (ii.state != 0) continue;
+                const std::pair<uint64_t, uint64_t> akey(ii.coord, ii.ref_strand);
+                if (hasher(akey) % T != t) continue;
+                auto it = sh.bucket_of.find(akey);
+                uint32_t b;
+                if (it == sh.bucket_of.end()) {
+                    b = (uint32_t)sh.bucket_entries.size();
+                    sh.bucket_of.emplace(akey, b);
+                    sh.bucket_entries.emplace_back();
+                    sh.umi_index.emplace_back();
+                    sh.bucket_first.push_back(ri);
+                } else {
+                    b = it->second;
+                }
+                auto &idx = sh.umi_index[b];
+                auto e = idx.find(ii.key);
+                if (e == idx.end()) { // Vacant :161-163
+                    idx.emplace(ii.key, (uint32_t)sh.entries.size());
+                    sh.bucket_entries[b].push_back((uint32_t)sh.entries.size());
+                    sh.entries.push_back({ii.key, ii.nmask, 1, ii.score, ri, b});
+                } else { // Occupied :164-175
+                    Entry &en = sh.entries[e->second];
+                    const bool keep_existing = merge == 0 ? true : en.score >= ii.score; // merge/mod.rs:21,35,49
+                    en.freq += 1;
+                    if (!keep_existing) { en.rep = ri; en.score = ii.score; }
+                }
+            }
+        });
         const double t_stage0 = now_s();
         std::fprintf(stderr, "UMI collapsing reading finished in %.3f seconds\n", t_stage0 - t_start); // :178-183
 
-        // canonical rank order inside each bucket: stable freq-descending (directional.rs:67-72)
-        const size_t n = entries.size(), nb = bucket_entries.size();
+        // buckets in order of first appearance; inside a bucket the stable freq-descending order
+        // of directional.rs:67-72 (creation order of a bucket's entries = first appearance)
+        struct BucketRef { uint32_t first, shard, local; };
+        std::vector<BucketRef> order;
+        size_t n = 0;
+        for (uint32_t t = 0; t < shards.size(); t++) {
+            n += shards[t].entries.size();
+            for (uint32_t b = 0; b < shards[t].bucket_entries.size(); b++)
+                order.push_back({shards[t].bucket_first[b], t, b});
+        }
+        std::sort(order.begin(), order.end(), [](const BucketRef &x, const BucketRef &y) { return x.first < y.first; });
+        const size_t nb = order.size();
         std::vector<uint64_t> keys(n), nmask(n), off(nb + 1, 0);
         std::vector<int32_t> freq(n);
         std::vector<uint32_t> rep(n);
         bool any_n = false;
         size_t w = 0, max_umi = 0;
         for (size_t b = 0; b < nb; b++) {
-            auto &v = bucket_entries[b];
-            std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return entries[y].freq < entries[x].freq; });
+            Shard &sh = shards[order[b].shard];
+            auto &v = sh.bucket_entries[order[b].local];
+            std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return sh.entries[y].freq < sh.entries[x].freq; });
             for (uint32_t ei : v) {
-                keys[w] = entries[ei].key; nmask[w] = entries[ei].nmask; freq[w] = entries[ei].freq; rep[w] = entries[ei].rep;
-                any_n |= entries[ei].nmask != 0;
+                const Entry &en = sh.entries[ei];
+                keys[w] = en.key; nmask[w] = en.nmask; freq[w] = en.freq; rep[w] = en.rep;
+                any_n |= en.nmask != 0;
                 w++;
             }
             off[b + 1] = w;
