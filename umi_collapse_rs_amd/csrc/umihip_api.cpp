@@ -115,6 +115,8 @@ struct umi_ctx {
     Plan plan;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
+    uint64_t *h_boff = nullptr;               // pinned staging of the bucket table
+    size_t h_boff_cap = 0;
     unsigned long long *h_counters = nullptr; // pinned
     uint32_t *h_changed = nullptr;            // pinned
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -340,11 +342,13 @@ class Pipeline {
         HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (ctx->h_counters[CNT_ERROR])
+        const unsigned long long bad =
+            ctx->h_counters[CNT_ERROR] + (ctx->h_counters[CNT_RISES] - ctx->h_counters[CNT_START_RISES]);
+        if (bad)
             return fail(UMI_ERR_ORDER,
                         "%llu entries break the input contract (freq < 1 or not in "
                         "freq-descending rank order inside a bucket)",
-                        ctx->h_counters[CNT_ERROR]);
+                        bad);
         return UMI_OK;
     }
 
@@ -381,7 +385,18 @@ class Pipeline {
     {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemcpyAsync(ctx->boff.p, bucket_off, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+        // the bucket table goes through a pinned buffer: a true async DMA instead of the
+        // runtime's staged copy of pageable memory (it is on the critical path of prep)
+        if (ctx->h_boff_cap < n_buckets + 1) {
+            if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
+            ctx->h_boff = nullptr;
+            ctx->h_boff_cap = 0;
+            const size_t want = (n_buckets + 1) + (n_buckets + 1) / 4 + 64;
+            HIP_TRY(hipHostMalloc((void **)&ctx->h_boff, want * 8));
+            ctx->h_boff_cap = want;
+        }
+        memcpy(ctx->h_boff, bucket_off, (n_buckets + 1) * 8);
+        HIP_TRY(hipMemcpyAsync(ctx->boff.p, ctx->h_boff, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
         if (mode == MODE_ADJACENCY && need_pairs) {
             HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
             HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
@@ -685,6 +700,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
     for (DevBuf *b : bufs) b->release();
+    if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
     for (int i = 0; i < 6; i++)

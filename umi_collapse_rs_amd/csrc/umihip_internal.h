@@ -30,6 +30,8 @@ enum Counter : int {
     CNT_ERROR = 2,      // prep validation failures
     CNT_KEPT = 3,       // survivors
     CNT_UNKNOWN = 4,    // adjacency collapse: undecided entries
+    CNT_RISES = 5,      // entries whose freq is above their predecessor's
+    CNT_START_RISES = 6, // ... of which sit at the start of a bucket (the only legal place)
     CNT_COUNT = 8,
 };
 

@@ -48,6 +48,20 @@ __device__ __forceinline__ int32_t threshold_of(float percentage, int32_t freq)
     return (int32_t)prod;
 }
 
+// sum `cnt` over the block (256 threads) and add it to *dst with one atomic
+__device__ __forceinline__ void block_count_add(unsigned int cnt, unsigned long long *dst)
+{
+    __shared__ unsigned int part[4];
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(dst, (unsigned long long)t);
+    }
+    __syncthreads(); // part[] may be reused by a second call
+}
+
 __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ keys,
                                                    const uint64_t *__restrict__ nmask,
                                                    const int32_t *__restrict__ freq,
@@ -59,6 +73,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
                                                    uint32_t *__restrict__ label,
                                                    unsigned long long *__restrict__ counters)
 {
+    unsigned int bad = 0, rises = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
         const uint64_t nm = nmask ? nmask[i] : 0ull;
@@ -75,18 +90,29 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
         } else {
             ((uint64_t *)fkey)[i] = k3;
         }
-        // contract check: freq >= 1, non-increasing inside a bucket
-        bool bad = f < 1;
-        if (i > 0 && f > freq[i - 1]) {
-            uint64_t lo = 0, hi = n_buckets; // largest b with bucket_off[b] <= i
-            while (lo < hi) {
-                uint64_t mid = (lo + hi + 1) >> 1;
-                if (bucket_off[mid] <= i) lo = mid; else hi = mid - 1;
-            }
-            if (bucket_off[lo] != i) bad = true;
-        }
-        if (bad) atomicAdd(&counters[CNT_ERROR], 1ull);
+        // contract check: freq >= 1 and non-increasing inside a bucket.  A rise is legal only
+        // at the first entry of a bucket: rises are counted here, rises at bucket starts by
+        // bucket_rise_kernel, and the host requires the two counts to agree (a per-entry
+        // search of the bucket table costs a chain of dependent loads in nearly every wave).
+        bad += f < 1 ? 1u : 0u;
+        rises += (i > 0 && f > freq[i - 1]) ? 1u : 0u;
     }
+    block_count_add(bad, &counters[CNT_ERROR]);
+    block_count_add(rises, &counters[CNT_RISES]);
+}
+
+__global__ __launch_bounds__(256) void bucket_rise_kernel(const int32_t *__restrict__ freq,
+                                                          const uint64_t *__restrict__ bucket_off,
+                                                          uint64_t n_buckets,
+                                                          unsigned long long *__restrict__ counters)
+{
+    unsigned int rises = 0;
+    for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets;
+         b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = bucket_off[b];
+        if (s > 0 && s < bucket_off[b + 1]) rises += freq[s] > freq[s - 1] ? 1u : 0u;
+    }
+    block_count_add(rises, &counters[CNT_START_RISES]);
 }
 
 // Edge list entries are (src, dst); SYM_FLAG on src marks a pair permitted in both
@@ -477,97 +503,101 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
                                                   int32_t adj_max_freq)
 {
     const int lane = threadIdx.x & 63;
-    {
-        uint64_t key[RL], nm[RL];
-        int32_t fr[RL], th[RL];
+    constexpr int H = 2 * RL; // the bucket's entries in halves of 32: half h = entries 32h..32h+31
+    uint64_t key[RL], nm[RL];
+    int32_t fr[RL], th[RL];
 #pragma unroll
-        for (int s = 0; s < RL; s++) {
-            const int r = lane + 64 * s;
-            const bool in_range = r < n;
-            key[s] = in_range ? keys[start + r] : 0ull;
-            nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
-            fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
-            th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+    for (int s = 0; s < RL; s++) {
+        const int r = lane + 64 * s;
+        const bool in_range = r < n;
+        key[s] = in_range ? keys[start + r] : 0ull;
+        nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
+        fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
+        th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+    }
+    // in[s][h]: bit jj set <=> entry j = 32h+jj may remove row (lane + 64s)
+    uint32_t in[RL][H];
+#pragma unroll
+    for (int s = 0; s < RL; s++)
+#pragma unroll
+        for (int h = 0; h < H; h++) in[s][h] = 0u;
+    const int lim = 2 * k + 1; // bit_count_xor / 2 <= k  <=>  bit_count_xor <= 2k+1
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        const int jn = min(32, n - 32 * h);
+        for (int jj = 0; jj < jn; jj++) {
+            const int src = 32 * (h & 1) + jj; // lane that holds entry j in slot h/2
+            const uint64_t kj = readlane64(key[h >> 1], src);
+            const uint64_t nj = HAS_N ? readlane64(nm[h >> 1], src) : 0ull;
+            const int32_t thj = __builtin_amdgcn_readlane(th[h >> 1], src);
+            const int j = 32 * h + jj;
+            const uint32_t bit = 1u << jj; // wave-uniform
+#pragma unroll
+            for (int s = 0; s < RL; s++) {
+                const uint64_t x = nm[s] ^ nj;
+                const int bcx = __builtin_popcountll(x | (key[s] ^ kj)) -
+                                (HAS_N ? __builtin_popcountll(x) / 3 : 0); // bitset.rs:85-87
+                bool e = bcx <= lim && (lane + 64 * s) != j;
+                if (MODE == MODE_DIRECTIONAL)
+                    e = e && fr[s] <= thj; // naive.rs:31 with max_freq = threshold(start)
+                else
+                    e = e && fr[s] <= adj_max_freq && (lane + 64 * s) > j;
+                in[s][h] |= e ? bit : 0u;
+            }
         }
-        // in[s][w]: bit jj set <=> entry j = 64w+jj may remove row (lane + 64s)
-        uint64_t in[RL][RL];
+    }
+    uint32_t lab[RL];
+#pragma unroll
+    for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+    if (MODE == MODE_DIRECTIONAL) {
+        bool changed;
+        do { // Gauss-Seidel sweeps in rank order until no label moves
+            uint32_t before[RL];
+#pragma unroll
+            for (int s = 0; s < RL; s++) before[s] = lab[s];
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                const int jn = min(32, n - 32 * h);
+                for (int jj = 0; jj < jn; jj++) {
+                    const uint32_t lj = __builtin_amdgcn_readlane(lab[h >> 1], 32 * (h & 1) + jj);
+                    const uint32_t bit = 1u << jj;
+#pragma unroll
+                    for (int s = 0; s < RL; s++) lab[s] = (in[s][h] & bit) ? min(lab[s], lj) : lab[s];
+                }
+            }
+            changed = false;
+#pragma unroll
+            for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
+        } while (__any(changed));
 #pragma unroll
         for (int s = 0; s < RL; s++)
+            if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
+    } else {
+        uint32_t alive[RL];
 #pragma unroll
-            for (int w = 0; w < RL; w++) in[s][w] = 0;
+        for (int s = 0; s < RL; s++) alive[s] = 1u;
 #pragma unroll
-        for (int w = 0; w < RL; w++) {
-            const int jn = min(64, n - 64 * w);
+        for (int h = 0; h < H; h++) {
+            const int jn = min(32, n - 32 * h);
             for (int jj = 0; jj < jn; jj++) {
-                const uint64_t kj = readlane64(key[w], jj);
-                const uint64_t nj = HAS_N ? readlane64(nm[w], jj) : 0ull;
-                const int32_t thj = __builtin_amdgcn_readlane(th[w], jj);
-                const int j = 64 * w + jj;
+                if (__builtin_amdgcn_readlane(alive[h >> 1], 32 * (h & 1) + jj)) { // j is a root (adjacency.rs:54)
+                    const uint32_t bit = 1u << jj;
 #pragma unroll
-                for (int s = 0; s < RL; s++) {
-                    const uint64_t x = nm[s] ^ nj;
-                    const int bcx = __builtin_popcountll(x | (key[s] ^ kj)) -
-                                    (HAS_N ? __builtin_popcountll(x) / 3 : 0);
-                    bool e = (bcx / 2) <= k && (lane + 64 * s) != j;
-                    if (MODE == MODE_DIRECTIONAL)
-                        e = e && fr[s] <= thj; // naive.rs:31 with max_freq = threshold(start)
-                    else
-                        e = e && fr[s] <= adj_max_freq && (lane + 64 * s) > j;
-                    in[s][w] |= e ? (1ull << jj) : 0ull;
-                }
-            }
-        }
-        uint32_t lab[RL];
-#pragma unroll
-        for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
-        if (MODE == MODE_DIRECTIONAL) {
-            bool changed;
-            do {
-                changed = false;
-#pragma unroll
-                for (int w = 0; w < RL; w++) {
-                    const int jn = min(64, n - 64 * w);
-                    for (int jj = 0; jj < jn; jj++) {
-                        const uint32_t lj = __builtin_amdgcn_readlane(lab[w], jj);
-#pragma unroll
-                        for (int s = 0; s < RL; s++) {
-                            if (((in[s][w] >> jj) & 1ull) && lj < lab[s]) {
-                                lab[s] = lj;
-                                changed = true;
-                            }
-                        }
-                    }
-                }
-            } while (__any(changed));
-#pragma unroll
-            for (int s = 0; s < RL; s++)
-                if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
-        } else {
-            uint32_t alive[RL];
-#pragma unroll
-            for (int s = 0; s < RL; s++) alive[s] = 1u;
-#pragma unroll
-            for (int w = 0; w < RL; w++) {
-                const int jn = min(64, n - 64 * w);
-                for (int jj = 0; jj < jn; jj++) {
-                    if (__builtin_amdgcn_readlane(alive[w], jj)) { // j is a root (adjacency.rs:54)
-#pragma unroll
-                        for (int s = 0; s < RL; s++) {
-                            if (((in[s][w] >> jj) & 1ull) && alive[s]) {
-                                alive[s] = 0u;
-                                lab[s] = (uint32_t)(64 * w + jj);
-                            }
+                    for (int s = 0; s < RL; s++) {
+                        if ((in[s][h] & bit) && alive[s]) {
+                            alive[s] = 0u;
+                            lab[s] = (uint32_t)(32 * h + jj);
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int s = 0; s < RL; s++)
-                if (lane + 64 * s < n) {
-                    label[start + lane + 64 * s] = start + lab[s];
-                    status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
-                }
         }
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+            if (lane + 64 * s < n) {
+                label[start + lane + 64 * s] = start + lab[s];
+                status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
+            }
     }
 }
 
@@ -661,19 +691,6 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
     if (any) changed[round] = 1;
 }
 
-// sum `cnt` over the block (256 threads) and add it to *dst with one atomic
-__device__ __forceinline__ void block_count_add(unsigned int cnt, unsigned long long *dst)
-{
-    __shared__ unsigned int part[4];
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int t = part[0] + part[1] + part[2] + part[3];
-        if (t) atomicAdd(dst, (unsigned long long)t);
-    }
-}
-
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ label,
                                                        uint32_t n, uint8_t *__restrict__ kept,
                                                        uint32_t *__restrict__ root,
@@ -761,6 +778,8 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
     prep_kernel<<<grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, bucket_off, n_buckets, n,
                                                  umi_len, percentage, key32 ? 1 : 0, fkey, thr,
                                                  label, counters);
+    bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
+                                                                     counters);
     return hipGetLastError();
 }
 
