@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=80_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="ctx option name=value (tuning)")
+    ap.add_argument("--split", action="store_true",
+                    help="N>1 only: strong scaling -- ONE giant position, its tile tasks split over "
+                         "the ranks, edge lists all-gathered, collapse replicated (default for N>1 "
+                         "is weak scaling: one position per rank)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE config per GPU: 2 = one giant position (headline), 3 = 10M reads "
                          "in 100k positions, 5 = 20-bp UMIs k=2 in many positions (parity-test "
@@ -112,7 +116,8 @@ def main():
 
     # ---- workload: position `rank` of the N-position job (config 2 per GPU)
     if args.config == 2:
-        st = synth.config2(seed=2 + 1000 * rank, n_reads=args.reads, umi_len=args.umi_len)
+        st = synth.config2(seed=2 + (0 if args.split else 1000 * rank), n_reads=args.reads,
+                           umi_len=args.umi_len)
         workload = ("BASELINE config 2 per GPU: %d reads, %d-bp UMIs, one alignment position "
                     "(uniform UMIs)" % (args.reads, args.umi_len))
     elif args.config == 3:
@@ -141,6 +146,9 @@ def main():
         assert sorted(int(p[0]) for p in parts) == list(range(world))
     w_total = w_local * world if args.config != 2 else sum(s * (s - 1) // 2 for s in sizes)
     reads_total = args.reads * world
+    split = args.split and world > 1
+    if split:  # every rank holds the same bucket: the job is ONE position
+        w_total, reads_total = w_local, args.reads
 
     d_keys = torch.from_numpy(st["keys"].view(np.int64)).to(dev)
     d_freq = torch.from_numpy(st["freq"]).to(dev)
@@ -156,7 +164,16 @@ def main():
         ctx.set_option(name, int(val))
     stream = torch.cuda.current_stream().cuda_stream
 
+    from umi_collapse_rs_amd.sharded import split_dedup_device
+
     def step():
+        if split:
+            s = split_dedup_device(ctx, dist, d_keys, None, d_freq, boff, args.umi_len, d_kept,
+                                   k=args.k, percentage=args.p)
+            for f in ("ms_prep", "ms_collapse", "ms_finalize"):
+                s.setdefault(f, 0.0)
+            s.setdefault("n_candidates", 0)
+            return s
         s = ctx.dedup_batch_device(d_keys.data_ptr(), 0, d_freq.data_ptr(), boff, args.umi_len,
                                    d_kept.data_ptr(), 0, k=args.k, percentage=args.p,
                                    stream=stream)
@@ -208,20 +225,23 @@ def main():
             if o.startswith("bs_unit="):
                 unit = int(o.split("=")[1])
         opp = ops_per_pair(args.umi_len, args.k, unit)
-        achieved = opp * w_local / (pair_ms * 1e-3) / 1e12
+        # --split: each rank's pair kernels cover 1/world of W
+        achieved = opp * (w_local / world if split else w_local) / (max(pair_ms, 1e-6) * 1e-3) / 1e12
         out = {
             "metric": "UMI-pair Hamming comparisons/s (12-bp UMIs, all-pairs adjacency + "
                       "directional collapse)",
             "value": w_total * args.steps / dt,
             "unit": "UMI-pair comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong" if split else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s, --data naive --algo dir -k %d -p %g" % (
                            workload, args.k, args.p),
                        "reads_per_position": args.reads, "positions": world,
                        "unique_umis_rank0": n, "pairs_W_total": w_total,
-                       "parallelism": "bucket-sharded x%d" % world},
+                       "parallelism": ("tile-task split x%d + edge all-gatherv" % world) if split
+                       else "bucket-sharded x%d" % world},
             "reads_per_s": reads_total * args.steps / dt,
             "host_buffer_path": None if host_ms is None else {
                 "ms_per_call": host_ms, "pairs_per_s": w_local / (host_ms * 1e-3),

@@ -122,6 +122,28 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                            int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
                            void *hip_stream, umi_stats *stats);
 
+/* ---- multi-GPU split of ONE call's all-pairs work (a single giant bucket
+ *      does not shard by buckets).  Each of n_parts ranks holds the same inputs on its own
+ *      GPU, evaluates every n_parts-th tile task and gets its share of the permitted-edge
+ *      list; the ranks all-gather their lists (RCCL) and every rank -- or one -- collapses the
+ *      union.  Entries of d_edges are (src | flag<<31, dst) pairs of uint32 packed in a uint64
+ *      and are opaque to the caller.  No counterpart in the reference (it has no second
+ *      device); the result equals umi_dedup_batch_device on the same inputs. ------------ */
+/* part in [0, n_parts), n_parts >= 2.  d_edges: caller's device buffer of edge_capacity
+ * entries; *n_edges_out = entries produced (if it exceeds edge_capacity: UMI_ERR_NOMEM,
+ * nothing copied, call again with a larger buffer). */
+int umi_pairs_partial_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                             const int32_t *d_freq, const uint64_t *bucket_off,
+                             uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
+                             int32_t adj_max_freq, uint32_t part, uint32_t n_parts,
+                             uint64_t *d_edges, uint64_t edge_capacity, uint64_t *n_edges_out,
+                             void *hip_stream, umi_stats *stats);
+/* Collapse of a gathered edge list over n entries (same index space as the calls that
+ * produced it): kept / root as in umi_dedup_batch_device. */
+int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges, uint64_t n_edges,
+                              int algo, uint8_t *d_kept, uint32_t *d_root, void *hip_stream,
+                              umi_stats *stats);
+
 /* ---- per-bucket path: 1:1 with trait DataStruct (src/data/mod.rs:11-17) as
  *      implemented by Naive (src/data/naive.rs).  UMIs are addressed by their
  *      index in the arrays handed to umi_data_new. -------------------------- */

@@ -50,6 +50,12 @@ SIGNATURES = {
                                          C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(Stats)]),
+    "umi_pairs_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u64p,
+                                           C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_uint64, _u64p, C.c_void_p, C.POINTER(Stats)]),
+    "umi_collapse_edges_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "umi_data_new": (C.c_int, [C.c_void_p, _u64p, _u64p, _i32p, C.c_uint32, C.c_int, C.c_int,
                                C.POINTER(C.c_void_p)]),
     "umi_data_remove_near": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int32, _u32p, _u32p]),

@@ -96,6 +96,31 @@ class Context:
         return st.as_dict()
 
 
+    def pairs_partial_device(self, d_keys, d_nmask, d_freq, bucket_off, umi_len, part, n_parts,
+                             d_edges, edge_capacity, k=1, percentage=0.5,
+                             algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0, stream=0):
+        """This rank's share (every n_parts-th tile task) of the permitted-edge list, written
+        to the caller's device buffer d_edges (uint64 entries).  Returns (n_edges, stats);
+        raises UmiHipError(UMI_ERR_NOMEM) if edge_capacity is too small (n_edges in the text)."""
+        bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+        st = Stats()
+        n_edges = C.c_uint64(0)
+        check(load().umi_pairs_partial_device(self._h, d_keys, d_nmask or None, d_freq,
+                                              ptr(bucket_off, C.c_uint64), len(bucket_off) - 1,
+                                              umi_len, k, percentage, algo, adj_max_freq, part,
+                                              n_parts, d_edges, edge_capacity, C.byref(n_edges),
+                                              stream or None, C.byref(st)))
+        return int(n_edges.value), st.as_dict()
+
+    def collapse_edges_device(self, n, d_edges, n_edges, d_kept, d_root=0,
+                              algo=UMI_ALGO_DIRECTIONAL, stream=0):
+        """Collapse of a gathered edge list over n entries; fills d_kept / d_root."""
+        st = Stats()
+        check(load().umi_collapse_edges_device(self._h, n, d_edges or None, n_edges, algo, d_kept,
+                                               d_root or None, stream or None, C.byref(st)))
+        return st.as_dict()
+
+
 _default_ctx = None
 
 

@@ -266,16 +266,17 @@ class Pipeline {
     Pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask, const int32_t *d_freq,
              const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len, int k,
              float percentage, int mode, int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
-             hipStream_t s)
+             hipStream_t s, uint32_t part = 0, uint32_t n_parts = 1)
         : ctx(ctx), d_keys(d_keys), d_nmask(d_nmask), d_freq(d_freq), bucket_off(bucket_off),
           n_buckets(n_buckets), n(n), umi_len(umi_len), k(k), percentage(percentage), mode(mode),
           adj_max_freq(adj_max_freq), d_kept(d_kept), d_root(d_root), s(s), pl(ctx->plan),
           key32(umi_len <= 16),
           need_pairs(!(mode == MODE_ADJACENCY && adj_max_freq < 1)), // reference adj: only the query goes
-          fused_max((mode == MODE_NEIGHBOURS || !need_pairs)
+          // the fused kernel collapses whole buckets itself: not when only an edge list is wanted
+          fused_max((mode == MODE_NEIGHBOURS || !need_pairs || n_parts > 1)
                         ? 0u
                         : std::min<uint32_t>(ctx->fused_max, FUSED_MAX)),
-          prof(ctx->profile)
+          prof(ctx->profile), part(part), n_parts(n_parts)
     {
         memset(&st, 0, sizeof(st));
         st.n_umis = n;
@@ -292,6 +293,8 @@ class Pipeline {
         if (rc == UMI_OK && stats) *stats = st;
         return rc;
     }
+
+    uint64_t edge_count() const { return n_edges; }
 
   private:
     umi_ctx *ctx;
@@ -311,6 +314,9 @@ class Pipeline {
     const bool key32, need_pairs;
     const uint32_t fused_max;
     const bool prof;
+    const uint32_t part, n_parts; // n_parts > 1: evaluate only every n_parts-th tile task, stop
+                                  // after the pair kernels (multi-GPU split of one call's pairs)
+    uint64_t task_counter = 0;    // running index over all tile tasks, for that split
     bool prune = false, drained = false;
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
@@ -328,13 +334,24 @@ class Pipeline {
         if (prune && (rc = prune_stage())) return rc;
         if ((rc = upload_bitsliced())) return rc;
         if ((rc = pair_stage())) return rc;
-        if (mode == MODE_NEIGHBOURS) return finish_neighbours();
+        if (mode == MODE_NEIGHBOURS || n_parts > 1) return finish_neighbours();
         if (mode == MODE_DIRECTIONAL || !need_pairs)
             rc = collapse_directional();
         else
             rc = collapse_adjacency();
         if (rc) return rc;
         return finish();
+    }
+
+    // keep this rank's share of a task list (round-robin over one running index: the tasks
+    // of a list are similar in size and adjacent ones touch the same tiles)
+    template <class T> void keep_my_share(std::vector<T> &v)
+    {
+        if (n_parts <= 1) return;
+        size_t w = 0;
+        for (size_t i = 0; i < v.size(); i++)
+            if ((task_counter++ % n_parts) == part) v[w++] = v[i];
+        v.resize(w);
     }
 
     int sync_counters()
@@ -359,6 +376,12 @@ class Pipeline {
                    umi_len, fused_max, ctx->prune, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
         if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
+        keep_my_share(pl.small_tasks);
+        keep_my_share(pl.big_tasks);
+        if (!prune) {
+            keep_my_share(pl.bs_tasks[0]);
+            keep_my_share(pl.bs_tasks[1]);
+        }
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
         int rc;
@@ -453,6 +476,8 @@ class Pipeline {
             o += cnt;
         }
         gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
+        keep_my_share(pl.bs_tasks[0]);
+        keep_my_share(pl.bs_tasks[1]);
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
         return UMI_OK;
@@ -560,6 +585,11 @@ class Pipeline {
             if (rc) return rc;
         }
         drained = true;
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&st.ms_prep, ctx->ev[0], ctx->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ctx->ev[1], ctx->ev[2]));
+            st.ms_total = st.ms_prep + st.ms_pairs;
+        }
         return UMI_OK;
     }
 
@@ -633,6 +663,106 @@ class Pipeline {
             HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
             HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
         }
+        return UMI_OK;
+    }
+};
+
+// Collapse of an edge list that is already on the device (the multi-GPU split gathers the
+// ranks' partial lists into one): labels start as the identity, then the same propagation /
+// greedy passes as the single-call pipeline.
+class EdgeCollapse {
+  public:
+    EdgeCollapse(umi_ctx *ctx, uint32_t n, const uint2 *d_edges, uint32_t n_edges, int mode,
+                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s)
+        : ctx(ctx), n(n), d_edges(d_edges), n_edges(n_edges), mode(mode), d_kept(d_kept),
+          d_root(d_root), s(s)
+    {
+    }
+    int run(umi_stats *stats)
+    {
+        HIP_TRY(hipSetDevice(ctx->device));
+        int rc = stages(stats);
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+
+  private:
+    umi_ctx *ctx;
+    uint32_t n;
+    const uint2 *d_edges;
+    uint32_t n_edges;
+    int mode;
+    uint8_t *d_kept;
+    uint32_t *d_root;
+    hipStream_t s;
+
+    int stages(umi_stats *stats)
+    {
+        int rc;
+        if ((rc = ctx->label.reserve((size_t)n * 4)) ||
+            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
+            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))))
+            return rc;
+        if (mode == MODE_ADJACENCY && ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))))
+            return rc;
+        unsigned long long *d_cnt = ctx->counters.as<unsigned long long>();
+        memset(ctx->h_counters, 0, CNT_COUNT * sizeof(unsigned long long));
+        ctx->h_counters[CNT_EDGES] = n_edges;
+        HIP_TRY(hipMemcpyAsync(d_cnt, ctx->h_counters, CNT_COUNT * sizeof(unsigned long long),
+                               hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_iota(ctx->label.as<uint32_t>(), n, s));
+        umi_stats st;
+        memset(&st, 0, sizeof(st));
+        st.n_umis = n;
+        st.n_edges = n_edges;
+        if (mode == MODE_DIRECTIONAL) {
+            if (n_edges) {
+                uint32_t *d_changed = ctx->changed.as<uint32_t>();
+                int rounds = 0, batch = 4;
+                for (;;) {
+                    HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
+                    for (int r = 0; r < batch; r++)
+                        HIP_TRY(launch_prop_round(d_edges, d_cnt, n_edges, ctx->label.as<uint32_t>(), n,
+                                                  d_changed, r, n_edges, s));
+                    HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch,
+                                           hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    bool done = false;
+                    for (int r = 0; r < batch && !done; r++) {
+                        rounds++;
+                        done = ctx->h_changed[r] == 0;
+                    }
+                    if (done) break;
+                    if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
+                    batch = std::min(2 * batch, MAX_ROUNDS_PER_SYNC);
+                }
+                st.n_rounds = (uint32_t)rounds;
+            }
+            HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+        } else {
+            uint8_t *d_status = ctx->status.as<uint8_t>(), *d_blocked = ctx->blocked.as<uint8_t>();
+            HIP_TRY(hipMemsetAsync(d_status, 0, n, s));
+            HIP_TRY(hipMemsetAsync(d_blocked, 0, n, s));
+            int iters = 0;
+            for (;;) {
+                HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UNKNOWN], 0, sizeof(unsigned long long), s));
+                HIP_TRY(launch_adj_iter(d_edges, d_cnt, n_edges, d_status, d_blocked,
+                                        ctx->label.as<uint32_t>(), n, d_cnt, n_edges, s));
+                HIP_TRY(hipMemcpyAsync(&ctx->h_counters[CNT_UNKNOWN], &d_cnt[CNT_UNKNOWN],
+                                       sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                iters++;
+                if (ctx->h_counters[CNT_UNKNOWN] == 0) break;
+                if (iters > MAX_ROUNDS) return fail(UMI_ERR_HIP, "adjacency collapse diverged");
+            }
+            st.n_rounds = (uint32_t)iters;
+            HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        st.n_kept = ctx->h_counters[CNT_KEPT];
+        if (stats) *stats = st;
         return UMI_OK;
     }
 };
@@ -787,6 +917,56 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                         k, percentage,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
                         adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats);
+}
+
+int umi_pairs_partial_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                             const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets,
+                             int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
+                             uint32_t part, uint32_t n_parts, uint64_t *d_edges,
+                             uint64_t edge_capacity, uint64_t *n_edges_out, void *hip_stream,
+                             umi_stats *stats)
+{
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    if (rc) return rc;
+    if (!n_edges_out) return fail(UMI_ERR_ARG, "n_edges_out is NULL");
+    if (n_parts < 2) return fail(UMI_ERR_ARG, "n_parts must be >= 2 (use umi_dedup_batch_device)");
+    if (part >= n_parts) return fail(UMI_ERR_ARG, "part %u outside 0..%u", part, n_parts - 1);
+    *n_edges_out = 0;
+    if (n == 0) return UMI_OK;
+    if (!d_keys || !d_freq) return fail(UMI_ERR_ARG, "keys/freq is NULL");
+    const int mode = algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY;
+    hipStream_t s = (hipStream_t)hip_stream;
+    Pipeline p(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len, k,
+               percentage, mode, adj_max_freq, nullptr, nullptr, s, part, n_parts);
+    if ((rc = p.run(stats))) return rc;
+    *n_edges_out = p.edge_count();
+    if (p.edge_count() > edge_capacity)
+        return fail(UMI_ERR_NOMEM, "edge buffer holds %llu entries, %llu needed",
+                    (unsigned long long)edge_capacity, (unsigned long long)p.edge_count());
+    if (p.edge_count()) {
+        if (!d_edges) return fail(UMI_ERR_ARG, "d_edges is NULL");
+        HIP_TRY(hipMemcpyAsync(d_edges, ctx->edges.p, p.edge_count() * sizeof(uint2),
+                               hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return UMI_OK;
+}
+
+int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges, uint64_t n_edges,
+                              int algo, uint8_t *d_kept, uint32_t *d_root, void *hip_stream,
+                              umi_stats *stats)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
+        return fail(UMI_ERR_ARG, "unknown algo %d", algo);
+    if (n >= 0x7FFFFFF0ull || n_edges >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "too many entries/edges");
+    if (n == 0) return UMI_OK;
+    if (!d_kept || (n_edges && !d_edges)) return fail(UMI_ERR_ARG, "kept/edges is NULL");
+    return EdgeCollapse(ctx, (uint32_t)n, (const uint2 *)d_edges, (uint32_t)n_edges,
+                        algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY, d_kept,
+                        d_root, (hipStream_t)hip_stream)
+        .run(stats);
 }
 
 int umi_dedup_batch(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,

@@ -134,6 +134,9 @@ hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *count
                              uint32_t edge_cap, uint32_t *label, uint32_t n, uint32_t *changed,
                              int round, uint32_t n_edges_hint, hipStream_t s);
 
+// label[i] = i (collapse of an external edge list)
+hipError_t launch_iota(uint32_t *label, uint32_t n, hipStream_t s);
+
 hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
                            unsigned long long *counters, hipStream_t s);
 

@@ -882,6 +882,21 @@ hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, con
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void iota_label_kernel(uint32_t *label, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        label[i] = i;
+}
+} // namespace
+
+hipError_t launch_iota(uint32_t *label, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    iota_label_kernel<<<grid_for(n, 256), 256, 0, s>>>(label, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *counters,
                              uint32_t edge_cap, uint32_t *label, uint32_t n, uint32_t *changed,
                              int round, uint32_t n_edges_hint, hipStream_t s)

@@ -109,3 +109,55 @@ def _global_index(bucket_off, buckets):
     if total == 0:
         return np.zeros(0, dtype=np.int64)
     return np.repeat(s - loff[:-1], n) + np.arange(total)
+
+
+def allgatherv_edges(local_edges, dist):
+    """all-gatherv of per-rank edge lists (int64 device tensors of different lengths): one
+    all_gather of the lengths, one padded all_gather of the payload (RCCL over xGMI when the
+    group is nccl).  Returns the concatenated list."""
+    import torch
+    world = dist.get_world_size()
+    dev = local_edges.device
+    cnt = torch.tensor([local_edges.numel()], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(1, max(counts))
+    buf = torch.zeros(mx, dtype=torch.int64, device=dev)
+    buf[: local_edges.numel()] = local_edges
+    out = torch.empty(world * mx, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)])
+
+
+def split_dedup_device(ctx, dist, d_keys, d_nmask, d_freq, bucket_off, umi_len, d_kept, d_root=None,
+                       k=1, percentage=0.5, algo=0, adj_max_freq=0, edge_capacity=None):
+    """One call's all-pairs work split over the ranks of `dist` (every rank holds the same
+    inputs on its GPU): rank r evaluates every world-th tile task, the permitted-edge lists are
+    all-gathered, every rank collapses the union.  For inputs that do not shard by buckets
+    (one giant alignment position).  d_* are torch device tensors."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = d_keys.numel()
+    stream = torch.cuda.current_stream().cuda_stream
+    cap = int(edge_capacity or max(1 << 20, 4 * n))
+    while True:
+        buf = torch.empty(cap, dtype=torch.int64, device=d_keys.device)
+        try:
+            ne, st = ctx.pairs_partial_device(
+                d_keys.data_ptr(), d_nmask.data_ptr() if d_nmask is not None else 0,
+                d_freq.data_ptr(), bucket_off, umi_len, rank, world, buf.data_ptr(), cap, k=k,
+                percentage=percentage, algo=algo, adj_max_freq=adj_max_freq, stream=stream)
+            break
+        except Exception as e:  # UMI_ERR_NOMEM: the message carries the count; grow and redo
+            if getattr(e, "code", 0) != -4:
+                raise
+            cap *= 4
+    edges = allgatherv_edges(buf[:ne], dist)
+    st2 = ctx.collapse_edges_device(n, edges.data_ptr() if edges.numel() else 0, edges.numel(),
+                                    d_kept.data_ptr(), d_root.data_ptr() if d_root is not None else 0,
+                                    algo=algo, stream=stream)
+    st2["n_pairs"] = st["n_pairs"]
+    st2["n_pairs_evaluated"] = st["n_pairs_evaluated"]
+    st2["ms_pairs"] = st.get("ms_pairs", 0.0)
+    return st2
