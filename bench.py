@@ -27,13 +27,24 @@ if ROOT not in sys.path:
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
-# and 32-row group, 2 ops per base for the mismatch planes plus the sticky counter per unit
-# of `unit` bases (0.5 / 1.5 / K+1 ops for K = 0 / 1 / >1), all full-rate 32-bit ops, for 32
-# pairs.  L = 12, k = 1, unit = 2: (24 + 9) / 32 = 1.03 (kernel K1b)
+# and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
+# counter over the L'/unit units: 0.5 per unit for K = 0, K+1 per unit for K > 1, and for
+# K = 1 the (any, two) tree of bs_pair_kernel (2 ops per triple of units, 2 per merge).
+# L = 12, k = 1, unit = 2: (24 + 6) / 32 = 0.94 lane-ops per pair (kernel K1b)
 def ops_per_pair(umi_len, k, unit=2):
     lp = 8 if umi_len <= 8 else 12 if umi_len <= 12 else 16 if umi_len <= 16 else 22
-    per_unit = 0.5 if k == 0 else 1.5 if k == 1 else k + 1.0
-    return (2.0 * lp + per_unit * (lp / unit)) / 32.0
+    units = lp // unit
+    if k == 0:
+        counter = 0.5 * units
+    elif k == 1:
+        full, rem = divmod(units, 3)
+        groups = full + (1 if rem else 0)
+        counter = 2 * full + (2 if rem == 2 else 0)   # or3 + majority / or + and
+        counter += sum(2 if (g < groups - 1 or rem != 1) else 1 for g in range(1, groups))
+        counter += max(0, groups - 2)                 # any_acc |= any between merges
+    else:
+        counter = (k + 1.0) * units
+    return (2.0 * lp + counter) / 32.0
 BYTES_PER_UMI = 16   # 8 B key + 4 B freq in, 4 B label out
 
 

@@ -399,13 +399,13 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
             cmask[w] = bit_of(fkey[c0 + c], (int)b) ? 0xFFFFFFFFu : 0u;
         }
         __syncthreads();
-        for (uint32_t c = COLSPLIT ? (uint32_t)(tid >> 6) : 0u; c < nc; c += COLSPLIT ? 4u : 1u) {
+        // hit masks of one column: h[g] = rows of group g within the filter's reach
+        auto column_hits = [&](uint32_t c, uint32_t (&h)[G]) -> uint32_t {
             uint32_t cm[NP];
 #pragma unroll
             for (int q = 0; q < NP / 4; q++)
                 *reinterpret_cast<uint4 *>(&cm[4 * q]) =
                     *reinterpret_cast<const uint4 *>(&cmask[c * NP + 4 * q]);
-            uint32_t h[G];
             uint32_t anyhit = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -422,29 +422,58 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
                     return m;
                 };
                 constexpr int U = LP / GB; // units per key
+                if (K == 1) {
+                    // ">= 2 mismatching units" as a tree: units in triples give (any, two) with
+                    // one or3 and one majority each; two groups merge as
+                    // two = twoA | twoB | (anyA & anyB).  6 ops for the 6 units of L' = 12.
+                    uint32_t any_acc = 0, two_acc = 0;
 #pragma unroll
-                for (int u = 0; u + 1 < U; u += 2) {
-                    const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
-                    if (K == 0) {
-                        s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
-                    } else if (K == 1) {
-                        // two units per step: >=2 of {s1, ma, mb} feeds s2
-                        s[2] |= BITOP3(s[1], ma, mb, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
-                        s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
-                    } else {
+                    for (int u = 0; u < U; u += 3) {
+                        const int rem = U - u < 3 ? U - u : 3;
+                        const bool last = u + 3 >= U;
+                        uint32_t any, two = 0;
+                        if (rem == 3) {
+                            const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1), mc = unit_mask(u + 2);
+                            any = BITOP3(ma, mb, mc, TT_A | TT_B | TT_C);
+                            two = BITOP3(ma, mb, mc, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                        } else if (rem == 2) {
+                            const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
+                            any = ma | mb;
+                            two = ma & mb;
+                        } else {
+                            any = unit_mask(u);
+                        }
+                        if (u == 0) {
+                            any_acc = any;
+                            two_acc = two;
+                        } else {
+                            if (rem >= 2) two_acc |= BITOP3(two, any_acc, any, TT_A | (TT_B & TT_C));
+                            else two_acc = BITOP3(two_acc, any_acc, any, TT_A | (TT_B & TT_C));
+                            if (!last) any_acc |= any;
+                        }
+                    }
+                    s[2] = two_acc;
+                } else {
+#pragma unroll
+                    for (int u = 0; u + 1 < U; u += 2) {
+                        const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
+                        if (K == 0) {
+                            s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
+                        } else {
+#pragma unroll
+                            for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
+                            s[1] |= ma;
+#pragma unroll
+                            for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], mb, TT_A | (TT_B & TT_C));
+                            s[1] |= mb;
+                        }
+                    }
+                    if (U % 2) { // odd unit count: the last unit alone
+                        const uint32_t ma = unit_mask(U - 1);
 #pragma unroll
                         for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
                         s[1] |= ma;
-#pragma unroll
-                        for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], mb, TT_A | (TT_B & TT_C));
-                        s[1] |= mb;
                     }
-                }
-                if (U % 2) { // odd unit count: the last unit alone
-                    const uint32_t ma = unit_mask(U - 1);
-#pragma unroll
-                    for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
-                    s[1] |= ma;
                 }
                 uint32_t hg = ~s[K + 1] & valid[g];
                 if (diag) { // only rows before the column: keeps the self pair and i > j out
@@ -455,18 +484,31 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
                 h[g] = hg;
                 anyhit |= hg;
             }
-            if (__any(anyhit != 0)) {
+            return anyhit;
+        };
+        auto emit_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
 #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    uint32_t hh = h[g];
-                    while (hh) {
-                        const int j = __builtin_ctz(hh);
-                        hh &= hh - 1;
-                        verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
-                                    &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
-                                    bucket_start + rbase[g] + j, c0 + c, a.perm);
-                    }
+            for (int g = 0; g < G; g++) {
+                uint32_t hh = h[g];
+                while (hh) {
+                    const int j = __builtin_ctz(hh);
+                    hh &= hh - 1;
+                    verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
+                                &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
+                                bucket_start + rbase[g] + j, c0 + c, a.perm);
                 }
+            }
+        };
+        // two columns per "any hit?" test: the test costs a VALU->scalar round trip per wave
+        constexpr uint32_t CSTEP = COLSPLIT ? 4u : 1u;
+        for (uint32_t c = COLSPLIT ? (uint32_t)(tid >> 6) : 0u; c < nc; c += 2 * CSTEP) {
+            uint32_t h0[G], h1[G];
+            uint32_t anyhit = column_hits(c, h0);
+            const bool second = c + CSTEP < nc; // wave-uniform
+            if (second) anyhit |= column_hits(c + CSTEP, h1);
+            if (__any(anyhit != 0)) {
+                emit_hits(c, h0);
+                if (second) emit_hits(c + CSTEP, h1);
             }
         }
         flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
