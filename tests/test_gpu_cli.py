@@ -50,3 +50,22 @@ def test_cli_variants_with_clips_strands_refs_and_n(tmp_path, extra, kw):
     exp, _ = bamio.expected_output(recs, **kw)
     assert oh == header
     assert orecs == exp
+
+
+def test_deep_position_with_and_without_pruning(tmp_path):
+    """One position with ~6,000 distinct 8-bp UMIs (bit-sliced tiles; label propagation over a
+    giant component): --data naive (plain all-pairs) and the default --data (range pruning) must
+    both give the reference restatement's records."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    header = bamio.make_header([("chr1", 1_000_000)])
+    recs = []
+    for i in range(9000):
+        umi = "".join("ACGT"[c] for c in rng.integers(0, 4, 8))
+        recs.append(bamio.make_record("r%d_%s" % (i, umi), 0, 0, 5000, int(rng.integers(0, 61)),
+                                      [("M", 50)], 50, bytes([30] * 50)))
+    exp, st = bamio.expected_output(recs, k=1, merge="mapqual")
+    assert len(st["keys"]) > 5000
+    for data in ("naive", "ngrambktree"):
+        oh, orecs, log = run_cli(tmp_path, header, recs, ["--data", data, "--num-threads", "4"])
+        assert orecs == exp, data

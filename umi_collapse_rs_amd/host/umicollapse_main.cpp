@@ -53,7 +53,8 @@ void usage()
               "      --umi_sep <BYTE>     Separator byte value between UMI and read name [default: 95]\n"
               "      --algo <ALGO>        adj or dir [default: dir]\n"
               "      --merge <MERGE>      any, avgqual or mapqual [default: mapqual in bam mode]\n"
-              "      --data <DATA>        accepted and ignored, as in the reference: Naive semantics\n"
+              "      --data <DATA>        every value gives Naive's result (as in the reference);\n"
+              "                           naive = plain all-pairs, others = + exact range pruning\n"
               "      --keep-unmapped      Keep unmapped reads\n"
               "      --two-pass --paired --remove-unpaired --remove-chimeric --tag   (see header)\n"
               "      --device <ID>        GPU to use [default: 0]");
@@ -322,6 +323,11 @@ int main(int argc, char **argv)
         if (!args.passthrough && n) {
             umi_ctx *ctx = nullptr;
             if (umi_ctx_create(args.device, &ctx) != UMI_OK) die(umi_last_error());
+            // The reference accepts every --data value and always runs Naive
+            // (deduplicate_sam.rs:210-213), so the result is the same for all of them.  Here
+            // "naive" is the plain all-pairs tile walk; any other value (the default is
+            // "ngrambktree") adds the exact range pruning of key-sorted tiles on deep positions.
+            if (umi_ctx_set_option(ctx, "prune", args.data != "naive") != UMI_OK) die(umi_last_error());
             t_gpu0 = now_s();
             if (umi_dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
                                 (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
