@@ -74,7 +74,8 @@ const char *umi_last_error(void);
  * the wave-per-chunk kernel), "bitslice" (0/1: use the bit-sliced tile kernel for
  * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
  * bit-sliced task), "fused_max" (largest bucket handled by the fused one-wave-per-bucket
- * kernel, 0..128, default 128), "bs_unit" (bases per counted unit of the bit-sliced filter:
+ * kernel, 0..128, default 128), "fused_sliced" (0/1: that kernel's bit-sliced body, default 1;
+ * it is used for k <= 3, the column-walking body otherwise), "bs_unit" (bases per counted unit of the bit-sliced filter:
  * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2),
  * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
  * cannot hold a pair within k -- same result, fewer comparisons executed).

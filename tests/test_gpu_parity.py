@@ -8,15 +8,18 @@ from helpers import canonical, random_bucket
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["default", "nofuse", "prune"])
+@pytest.fixture(scope="module", params=["default", "nofuse", "prune", "fused_walk"])
 def ctx(request):
     """default: fused one-wave kernel for buckets <= 128, popcount chunks to 1024, bit-sliced
     tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list.
-    prune: every bucket > 128 through key-sorted bit-sliced tiles with range pruning."""
+    prune: every bucket > 128 through key-sorted bit-sliced tiles with range pruning.
+    fused_walk: the fused kernel's column-walking body instead of its bit-sliced one."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
     if request.param == "nofuse":
         c.set_option("fused_max", 0)
+    if request.param == "fused_walk":
+        c.set_option("fused_sliced", 0)
     if request.param == "prune":
         c.set_option("prune", 1)
         c.set_option("small_max", 128)
@@ -79,6 +82,25 @@ def test_random_buckets_directional(ctx, L, k, p, n_frac):
     rng = np.random.default_rng(100 * L + 7 * k + int(10 * p))
     keys, nm, fr, off = make_batch(rng, 60, L, 40, err=0.06, n_frac=n_frac)
     check_against_oracle(ctx, keys, nm, fr, off, L, k, p)
+
+
+@pytest.mark.parametrize("p", [-0.5, -0.0, 2.0, 1e9, -1e9, float("inf"), float("-inf"), float("nan")])
+def test_threshold_edge_cases(ctx, p):
+    """directional.rs:100-102 on odd inputs: a negative percentage makes the thresholds rise
+    with rank, freq = i32::MAX wraps freq + 1 and the cast saturates / maps NaN to 0.  The
+    fused kernel's prefix search must notice that the thresholds are out of order."""
+    rng = np.random.default_rng(4242)
+    keys, nm, fr, off = make_batch(rng, 40, 8, 45, err=0.08, n_frac=0.01)
+    keys2, nm2, fr2, off2 = make_batch(rng, 3, 9, 500, err=0.05, exact=True)
+    for kk, mm, ff, oo, L in ((keys, nm, fr, off, 8), (keys2, nm2, fr2, off2, 9)):
+        for k in (1, 2):
+            check_against_oracle(ctx, kk, mm, ff, oo, L, k, p)
+        big = ff.copy() # the top entries of every bucket at and next to i32::MAX
+        starts = oo[:-1][np.diff(oo.astype(np.int64)) > 3].astype(np.int64)
+        big[starts] = 0x7FFFFFFF
+        big[starts + 1] = 0x7FFFFFFF
+        big[starts + 2] = 0x7FFFFFFE
+        check_against_oracle(ctx, kk, mm, big, oo, L, 1, p)
 
 
 @pytest.mark.parametrize("amf", [0, 1, 2, 1 << 30])

@@ -106,6 +106,7 @@ struct umi_ctx {
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
     uint32_t fused_max = FUSED_MAX;
+    bool fused_sliced = true;
     int bs_unit = 2;
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
@@ -329,8 +330,11 @@ class Pipeline {
     int run_stages()
     {
         int rc;
-        if ((rc = plan_and_reserve())) return rc;
+        // prep needs nothing from the plan: it is enqueued first, and the host walks the bucket
+        // table (tile tasks, pair counts) while the bucket table uploads and prep runs
+        if ((rc = reserve_core())) return rc;
         if ((rc = upload_and_prep())) return rc;
+        if ((rc = plan_and_upload_tasks())) return rc;
         if (prune && (rc = prune_stage())) return rc;
         if ((rc = upload_bitsliced())) return rc;
         if ((rc = pair_stage())) return rc;
@@ -369,8 +373,25 @@ class Pipeline {
         return UMI_OK;
     }
 
-    // host planning + workspace
-    int plan_and_reserve()
+    // workspace whose size follows from n and n_buckets alone
+    int reserve_core()
+    {
+        int rc;
+        if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
+            (rc = ctx->label.reserve((size_t)n * 4)) ||
+            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
+            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
+            (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
+            return rc;
+        if (mode == MODE_ADJACENCY && need_pairs)
+            if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
+        d_cnt = ctx->counters.as<unsigned long long>();
+        bs_fkey = ctx->fkey.p;
+        return UMI_OK;
+    }
+
+    // host planning (overlaps the prep kernels) + the popcount kernels' task lists
+    int plan_and_upload_tasks()
     {
         build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
                    umi_len, fused_max, ctx->prune, pl);
@@ -385,25 +406,23 @@ class Pipeline {
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
         int rc;
-        if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
-            (rc = ctx->label.reserve((size_t)n * 4)) ||
-            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
-            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
-            (rc = ctx->boff.reserve((n_buckets + 1) * 8)) ||
-            (rc = ctx->tasks.reserve(std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) *
+        if ((rc = ctx->tasks.reserve(std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) *
                                      sizeof(PairTask))) ||
             (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
                                            sizeof(PlaneTask))) ||
             (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
             return rc;
-        if (mode == MODE_ADJACENCY && need_pairs)
-            if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
-        d_cnt = ctx->counters.as<unsigned long long>();
-        bs_fkey = ctx->fkey.p;
+        PairTask *d_tasks = ctx->tasks.as<PairTask>();
+        if (!pl.small_tasks.empty())
+            HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
+                                   pl.small_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
+        if (!pl.big_tasks.empty())
+            HIP_TRY(hipMemcpyAsync(d_tasks + pl.small_tasks.size(), pl.big_tasks.data(),
+                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
         return UMI_OK;
     }
 
-    // counters, bucket table, popcount-kernel tasks; filter keys / thresholds / labels
+    // counters, bucket table; filter keys / thresholds / labels
     int upload_and_prep()
     {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
@@ -424,13 +443,6 @@ class Pipeline {
             HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
             HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
         }
-        PairTask *d_tasks = ctx->tasks.as<PairTask>();
-        if (!pl.small_tasks.empty())
-            HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
-                                   pl.small_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
-        if (!pl.big_tasks.empty())
-            HIP_TRY(hipMemcpyAsync(d_tasks + pl.small_tasks.size(), pl.big_tasks.data(),
-                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
                             percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
                             ctx->label.as<uint32_t>(), d_cnt, s));
@@ -516,7 +528,8 @@ class Pipeline {
         if (pl.n_fused) {
             HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
                                          ctx->boff.as<uint64_t>(), (uint32_t)n_buckets, fused_max,
-                                         ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k, mode,
+                                         ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k,
+                                         umi_len, ctx->fused_sliced, mode,
                                          adj_max_freq, s));
             st.n_pair_launches += 1;
         }
@@ -852,6 +865,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "bs_unit")) {
         if (value < 1 || value > 3) return fail(UMI_ERR_ARG, "bs_unit must be 1, 2 or 3");
         ctx->bs_unit = (int)value;
+    } else if (!strcmp(name, "fused_sliced")) {
+        ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
         ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);

@@ -122,11 +122,12 @@ hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32
                        hipStream_t s);
 
 // all-pairs + collapse of whole small buckets (2..fused_max entries), one wave per bucket;
-// walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[])
+// walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[]).
+// sliced: use the bit-sliced body when k <= 3
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k, int mode,
-                                int32_t adj_max_freq, hipStream_t s);
+                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
+                                int umi_len, bool sliced, int mode, int32_t adj_max_freq, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a
 // no-op on the device when round r-1 changed nothing.

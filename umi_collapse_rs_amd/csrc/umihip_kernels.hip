@@ -643,10 +643,244 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
     }
 }
 
+// ---- the same, with the distances bit-sliced over the bucket's columns -------------
+// A lane still owns one row (two for 65..128 entries), but instead of walking the columns one
+// by one it meets 64 of them at a time: for base i the two code bits of all entries are
+// wave-wide ballots (P0, P1: one bit per column), the lane XORs them with its own two code
+// bits and feeds a sticky counter of mismatching bases in v_bitop3 -- 8 wave-instructions per
+// base for 64 pairs per lane instead of ~17 per column.  ~s[K+1] is the row's set of columns
+// within distance K (exact on N-free keys; with N the hits are re-checked exactly through
+// ds_bpermute).  The permitted in-edges follow from one binary search per row when thr[] is
+// non-increasing inside the bucket (it is unless percentage < 0 or freq + 1 wrapped; the wave
+// checks): {j : freq[i] <= thr[j]} is then a prefix.  The collapse then sweeps only over the entries that have an out-edge at all.
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off);
+    return v;
+}
+
+template <int RL, bool HAS_N, int MODE, int K>
+__device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict__ keys,
+                                                     const uint64_t *__restrict__ nmask,
+                                                     const int32_t *__restrict__ freq,
+                                                     const int32_t *__restrict__ thr, uint32_t start,
+                                                     int n, int umi_len, uint32_t *__restrict__ label,
+                                                     uint8_t *__restrict__ status,
+                                                     int32_t adj_max_freq)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr int H = 2 * RL; // column halves of 32
+    uint64_t key[RL], nm[RL], fold[RL];
+    int32_t fr[RL], th[RL];
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int r = lane + 64 * s;
+        const bool in_range = r < n;
+        key[s] = in_range ? keys[start + r] : 0ull;
+        nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
+        fold[s] = key[s] & ~nm[s]; // N folded onto A: the sliced distance never exceeds the exact one
+        fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
+        th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+    }
+    // cnt[s][h][l]: columns of half h at which row (lane + 64 s) has more than l mismatches so far
+    uint32_t cnt[RL][H][K + 1];
+#pragma unroll
+    for (int s = 0; s < RL; s++)
+#pragma unroll
+        for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int l = 0; l <= K; l++) cnt[s][h][l] = 0u;
+    for (int i = 0; i < umi_len; i++) {
+        uint32_t r0[RL], r1[RL]; // this row's two code bits of base i, spread over a word
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            r0[s] = 0u - (uint32_t)((fold[s] >> (3 * i)) & 1ull);
+            r1[s] = 0u - (uint32_t)((fold[s] >> (3 * i + 1)) & 1ull);
+        }
+#pragma unroll
+        for (int w = 0; w < RL; w++) {
+            const unsigned long long p0 = __ballot((int)(r0[w] & 1u));
+            const unsigned long long p1 = __ballot((int)(r1[w] & 1u));
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t c0 = (uint32_t)(p0 >> (32 * hh)), c1 = (uint32_t)(p1 >> (32 * hh));
+#pragma unroll
+                for (int s = 0; s < RL; s++) {
+                    const uint32_t m = BITOP3(c0 ^ r0[s], c1, r1[s], TT_A | (TT_B ^ TT_C));
+#pragma unroll
+                    for (int l = K; l >= 1; l--)
+                        cnt[s][2 * w + hh][l] = BITOP3(cnt[s][2 * w + hh][l], cnt[s][2 * w + hh][l - 1], m,
+                                                       TT_A | (TT_B & TT_C));
+                    cnt[s][2 * w + hh][0] |= m;
+                }
+            }
+        }
+    }
+    uint32_t in[RL][H];
+#pragma unroll
+    for (int s = 0; s < RL; s++)
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            const int nv = n - 32 * h; // valid columns in this half
+            const uint32_t colvalid = nv >= 32 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+            in[s][h] = ~cnt[s][h][K] & colvalid;
+        }
+    if (HAS_N) { // exact re-check of the hits (bitset.rs:85-87), column values through ds_bpermute
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                uint32_t todo = in[s][h];
+                while (__any(todo != 0)) { // all lanes stay in the loop: bpermute needs its sources
+                    const int jj = todo ? __builtin_ctz(todo) : 0;
+                    const int src = 32 * (h & 1) + jj;
+                    const uint64_t kj = ((uint64_t)(uint32_t)__shfl((int)(key[h >> 1] >> 32), src) << 32) |
+                                        (uint32_t)__shfl((int)key[h >> 1], src);
+                    const uint64_t nj = ((uint64_t)(uint32_t)__shfl((int)(nm[h >> 1] >> 32), src) << 32) |
+                                        (uint32_t)__shfl((int)nm[h >> 1], src);
+                    if (todo) {
+                        const uint64_t x = nm[s] ^ nj;
+                        const int bcx = __builtin_popcountll(x | (key[s] ^ kj)) - __builtin_popcountll(x) / 3;
+                        if (bcx > 2 * K + 1) in[s][h] &= ~(1u << jj);
+                        todo &= todo - 1;
+                    }
+                }
+            }
+    }
+    // which sources may remove this row: freq condition + not itself.  freq is non-increasing
+    // inside a bucket, so thr is too unless percentage < 0 or freq + 1 wrapped (directional.rs:
+    // 100-102): then {j : freq[row] <= thr[j]} is a prefix and one binary search finds its end.
+    bool monotone = true;
+    if (MODE == MODE_DIRECTIONAL) {
+        bool rise = false;
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            int32_t prev = __shfl_up(th[s], 1);
+            if (lane == 0) prev = s == 0 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(th[0], 63);
+            rise |= th[s] > prev;
+        }
+        monotone = !__any(rise);
+    }
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int row = lane + 64 * s;
+        int q = 0; // sources 0..q-1 pass the freq test
+        if (MODE == MODE_DIRECTIONAL) {
+            if (monotone) {
+                // first j with thr[j] < freq[row] (naive.rs:31 with max_freq = threshold(start)):
+                // every source before it may remove this row
+                int lo = 0, hi = n;
+#pragma unroll
+                for (int it = 0; it < (RL == 1 ? 7 : 8); it++) {
+                    const int mid = min((lo + hi) >> 1, n - 1);
+                    int t = __shfl(th[0], mid & 63);
+                    if (RL == 2) {
+                        const int t1 = __shfl(th[RL - 1], mid & 63);
+                        t = mid >= 64 ? t1 : t;
+                    }
+                    if (lo < hi) {
+                        if (t >= fr[s]) lo = mid + 1; else hi = mid;
+                    }
+                }
+                q = lo;
+            }
+        } else {
+            q = fr[s] <= adj_max_freq ? row : 0; // adjacency.rs:56: only earlier roots, freq <= max_freq
+        }
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            uint32_t pre;
+            if (MODE == MODE_DIRECTIONAL && !monotone) {
+                pre = 0u; // thresholds out of order: test every source (wave-uniform branch)
+                const int jn = min(32, n - 32 * h);
+                for (int jj = 0; jj < jn; jj++) {
+                    const int32_t thj = __builtin_amdgcn_readlane(th[h >> 1], 32 * (h & 1) + jj);
+                    pre |= fr[s] <= thj ? 1u << jj : 0u;
+                }
+            } else {
+                const int nb = q - 32 * h;
+                pre = nb >= 32 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+            }
+            uint32_t self = 0u;
+            if (row >= 32 * h && row < 32 * h + 32) self = 1u << (row - 32 * h);
+            in[s][h] &= pre & ~self;
+            if (row >= n) in[s][h] = 0u;
+        }
+    }
+    // sources that have an out-edge at all (wave-uniform)
+    uint32_t act[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int s = 0; s < RL; s++) v |= in[s][h];
+        act[h] = __builtin_amdgcn_readfirstlane(wave_or(v));
+    }
+    uint32_t lab[RL];
+#pragma unroll
+    for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+    if (MODE == MODE_DIRECTIONAL) {
+        bool changed;
+        do { // Gauss-Seidel sweeps in rank order over the active sources until no label moves
+            uint32_t before[RL];
+#pragma unroll
+            for (int s = 0; s < RL; s++) before[s] = lab[s];
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                uint32_t todo = act[h];
+                while (todo) {
+                    const int jj = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const uint32_t lj = __builtin_amdgcn_readlane(lab[h >> 1], 32 * (h & 1) + jj);
+                    const uint32_t bit = 1u << jj;
+#pragma unroll
+                    for (int s = 0; s < RL; s++) lab[s] = (in[s][h] & bit) ? min(lab[s], lj) : lab[s];
+                }
+            }
+            changed = false;
+#pragma unroll
+            for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
+        } while (__any(changed));
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+            if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
+    } else {
+        uint32_t alive[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) alive[s] = 1u;
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            uint32_t todo = act[h];
+            while (todo) {
+                const int jj = __builtin_ctz(todo);
+                todo &= todo - 1;
+                if (__builtin_amdgcn_readlane(alive[h >> 1], 32 * (h & 1) + jj)) { // j is a root
+                    const uint32_t bit = 1u << jj;
+#pragma unroll
+                    for (int s = 0; s < RL; s++) {
+                        if ((in[s][h] & bit) && alive[s]) {
+                            alive[s] = 0u;
+                            lab[s] = (uint32_t)(32 * h + jj);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+            if (lane + 64 * s < n) {
+                label[start + lane + 64 * s] = start + lab[s];
+                status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
+            }
+    }
+}
+
 // Walks the bucket table itself (no task list to build or upload): wave w takes buckets
 // w, w + n_waves, ...; buckets with fewer than 2 or more than fused_max entries belong
 // to other kernels and are skipped.
-template <bool HAS_N, int MODE>
+// KB >= 0: bit-sliced body with K = KB (k <= 3); KB < 0: the column-walking body (any k).
+template <bool HAS_N, int MODE, int KB>
 __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
                                                            const uint64_t *__restrict__ nmask,
                                                            const int32_t *__restrict__ freq,
@@ -655,7 +889,7 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
                                                            uint32_t n_buckets, uint32_t fused_max,
                                                            uint32_t *__restrict__ label,
                                                            uint8_t *__restrict__ status, int k,
-                                                           int32_t adj_max_freq)
+                                                           int umi_len, int32_t adj_max_freq)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -664,12 +898,22 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
         const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b + 1]);
         const uint32_t n = end - start;
         if (n < 2 || n > fused_max) continue;
-        if (n <= 64)
-            small_bucket_body<1, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
-                                              adj_max_freq);
-        else
-            small_bucket_body<2, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
-                                              adj_max_freq);
+        if (KB >= 0) {
+            constexpr int K = KB >= 0 ? KB : 0;
+            if (n <= 64)
+                small_bucket_body_bs<1, HAS_N, MODE, K>(keys, nmask, freq, thr, start, (int)n, umi_len,
+                                                        label, status, adj_max_freq);
+            else
+                small_bucket_body_bs<2, HAS_N, MODE, K>(keys, nmask, freq, thr, start, (int)n, umi_len,
+                                                        label, status, adj_max_freq);
+        } else {
+            if (n <= 64)
+                small_bucket_body<1, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
+                                                  adj_max_freq);
+            else
+                small_bucket_body<2, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
+                                                  adj_max_freq);
+        }
     }
 }
 
@@ -899,27 +1143,42 @@ hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool 
     return hipGetLastError();
 }
 
+namespace {
+template <bool HAS_N, int MODE>
+void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_t *nmask,
+                    const int32_t *freq, const int32_t *thr, const uint64_t *bucket_off,
+                    uint32_t n_buckets, uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
+                    int umi_len, int32_t adj_max_freq, hipStream_t s)
+{
+#define UMI_LAUNCH_SMALL(KB)                                                                      \
+    small_bucket_kernel<HAS_N, MODE, KB><<<blocks, 256, 0, s>>>(keys, nmask, freq, thr, bucket_off, \
+                                                                n_buckets, fused_max, label, status, \
+                                                                k, umi_len, adj_max_freq)
+    switch (kb) {
+    case 0: UMI_LAUNCH_SMALL(0); break;
+    case 1: UMI_LAUNCH_SMALL(1); break;
+    case 2: UMI_LAUNCH_SMALL(2); break;
+    case 3: UMI_LAUNCH_SMALL(3); break;
+    default: UMI_LAUNCH_SMALL(-1); break;
+    }
+#undef UMI_LAUNCH_SMALL
+}
+} // namespace
+
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k, int mode,
-                                int32_t adj_max_freq, hipStream_t s)
+                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
+                                int umi_len, bool sliced, int mode, int32_t adj_max_freq, hipStream_t s)
 {
     if (n_buckets == 0 || fused_max < 2) return hipSuccess;
     const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, 256 * 8);
+    const int kb = (sliced && k >= 0 && k <= 3) ? k : -1;
     if (mode == MODE_DIRECTIONAL) {
-        if (nmask)
-            small_bucket_kernel<true, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
-                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
-        else
-            small_bucket_kernel<false, MODE_DIRECTIONAL><<<blocks, 256, 0, s>>>(
-                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
+        if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
+        else launch_small_k<false, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
     } else {
-        if (nmask)
-            small_bucket_kernel<true, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
-                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
-        else
-            small_bucket_kernel<false, MODE_ADJACENCY><<<blocks, 256, 0, s>>>(
-                keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, adj_max_freq);
+        if (nmask) launch_small_k<true, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
+        else launch_small_k<false, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
     }
     return hipGetLastError();
 }
