@@ -48,13 +48,14 @@ def make_header(refs, text=None):
     return h
 
 
-def make_record(qname, flag, tid, pos, mapq, cigar, seq_len, quals, tags=b""):
+def make_record(qname, flag, tid, pos, mapq, cigar, seq_len, quals, tags=b"", mtid=-1, mpos=-1,
+                tlen=0):
     """cigar: list of (op_char, len).  Sequence content is irrelevant to the path: all A."""
     qn = qname.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (l << 4) | CIGAR_OPS.index(op)) for op, l in cigar)
     seq = bytes((seq_len + 1) // 2)
     body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, 4680, len(cigar), flag, seq_len,
-                       -1, -1, 0) + qn + cig + seq + bytes(quals) + tags
+                       mtid, mpos, tlen) + qn + cig + seq + bytes(quals) + tags
     return struct.pack("<i", len(body)) + body
 
 
@@ -76,14 +77,16 @@ def split_records(stream):
 
 
 def parse_record(rec):
-    tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", rec, 4)
+    tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from(
+        "<iiBBHHHiiii", rec, 4)
     o = 4 + 32
     qname = rec[o:o + l_rn - 1]
     o += l_rn
     cigar = [(CIGAR_OPS[v & 0xf], v >> 4) for v in struct.unpack_from("<%dI" % n_cig, rec, o)]
     o += 4 * n_cig + (l_seq + 1) // 2
     qual = rec[o:o + l_seq]
-    return dict(tid=tid, pos=pos, mapq=mapq, flag=flag, qname=qname, cigar=cigar, qual=qual)
+    return dict(tid=tid, pos=pos, mapq=mapq, flag=flag, qname=qname, cigar=cigar, qual=qual,
+                mtid=mtid, mpos=mpos, tlen=tlen)
 
 
 def unclipped_pos(r):
@@ -122,18 +125,39 @@ def detect_umi_length(qname, sep):
     raise ValueError("No UMI group found in pattern match")
 
 
-def stage_like_reference(recs, merge="mapqual", umi_len=0, sep=95, keep_unmapped=False):
+def stage_like_reference(recs, merge="mapqual", umi_len=0, sep=95, keep_unmapped=False,
+                         paired=False, remove_unpaired=False, remove_chimeric=False):
     """Read loop of src/deduplicate_sam.rs:93-177 + canonical order, through the oracle's
-    staging.  Returns (staged dict incl. umi_len, pre-written record indices)."""
+    staging.  Returns (staged dict incl. umi_len and counters, pre-written record indices)."""
     bucket_ids, umis, scores, rec_idx, pre = [], [], [], [], []
     key_to_bucket = {}
+    counters = dict(total=0, unmapped=0, unpaired=0, chimeric=0)
     for i, rec in enumerate(recs):
         r = parse_record(rec)
+        is_paired = bool(r["flag"] & 0x1)
+        if paired and is_paired and r["flag"] & 0x80:      # second mates: :95-97
+            continue
+        counters["total"] += 1
         if r["flag"] & 0x4:
+            counters["unmapped"] += 1
             if keep_unmapped:
                 pre.append(i)
             continue
+        if paired:                                         # :110-129
+            if not is_paired:
+                counters["unpaired"] += 1
+                if remove_unpaired:
+                    continue
+            if is_paired and r["flag"] & 0x8:
+                counters["unmapped"] += 1
+                continue
+            if is_paired and r["tid"] != r["mtid"]:
+                counters["chimeric"] += 1
+                if remove_chimeric:
+                    continue
         akey = (bool(r["flag"] & 0x10), unclipped_pos(r), r["tid"])
+        if paired:
+            akey += (r["tlen"],)                           # PairedAlignment, :547-553
         b = key_to_bucket.setdefault(akey, len(key_to_bucket))
         if umi_len == 0:
             umi_len = detect_umi_length(r["qname"], sep)
@@ -147,7 +171,42 @@ def stage_like_reference(recs, merge="mapqual", umi_len=0, sep=95, keep_unmapped
     st = orc.stage_reads(bucket_ids, ub, scores, max(umi_len, 1), merge=0 if merge == "any" else 1)
     st["rep"] = np.array(rec_idx, dtype=np.int64)[st["rep"].astype(np.int64)] if len(rec_idx) else st["rep"]
     st["umi_len"] = umi_len
+    st["counters"] = counters
     return st, pre
+
+
+def paired_writer(recs, survivors):
+    """UcWriter of src/deduplicate_sam.rs:382-459 over the survivors (record indices in output
+    order): a written paired record registers (qname, mate ref, mate pos); whenever the
+    reference of the written records changes, and at close, the input is re-read and the second
+    mates that are registered are written (and unregistered).  The coordinate is treated as
+    part of the identity (the reference hashes it, :298-318)."""
+    parsed = [parse_record(r) for r in recs]
+
+    def write_reversed(ref, full):
+        for j, m in enumerate(parsed):
+            f = m["flag"]
+            if f & 0x4 or not f & 0x1 or not f & 0x80 or f & 0x8:
+                continue
+            if not full and m["tid"] != ref:
+                continue
+            key = (m["qname"], m["tid"], m["pos"])
+            if key in waiting:
+                out.append(j)
+                waiting.discard(key)
+
+    out, waiting, cur = [], set(), None
+    for i in survivors:
+        r = parsed[i]
+        if cur is not None and cur != r["tid"]:
+            write_reversed(cur, False)
+        cur = r["tid"]
+        if r["flag"] & 0x1:
+            waiting.add((r["qname"], r["mtid"], r["mpos"]))
+        out.append(i)
+    if cur is not None:
+        write_reversed(cur, True)
+    return out
 
 
 def expected_output(recs, k=1, p=0.5, algo="dir", **kw):
@@ -155,7 +214,56 @@ def expected_output(recs, k=1, p=0.5, algo="dir", **kw):
     kept, _, _ = orc.dedup_batch(st["keys"], st["nmask"], st["freq"], st["bucket_off"],
                                  st["umi_len"], k, p, 0 if algo == "dir" else 1)
     out = list(pre) + [int(st["rep"][i]) for i in np.nonzero(kept)[0]]
+    if kw.get("paired"):
+        out = paired_writer(recs, out)
     return [recs[i] for i in out], st
+
+
+def synthetic_paired_bam(seed, n_positions, pairs_per_position, umi_len=10, err=0.03):
+    """Coordinate-sorted paired-end BAM over two references: proper pairs with a few distinct
+    template lengths per position, plus unpaired reads, pairs with an unmapped mate, chimeric
+    pairs (mate on the other reference), unmapped reads and a duplicated second mate."""
+    from umi_collapse_rs_amd import synth
+    rng = np.random.default_rng(seed)
+    pos, bases = synth.molecule_reads(seed, n_positions, pairs_per_position, umi_len, err=err)
+    refs = [("chr1", 10_000_000), ("chr2", 5_000_000)]
+    items = []  # (tid, pos, order, record)
+    for i in range(len(pos)):
+        umi = synth.BASES[bases[i]].tobytes().decode()
+        name = "p%d_%s" % (i, umi)
+        tid = 0 if pos[i] % 3 else 1
+        p0 = 1000 + 20 * int(pos[i])
+        tl = int(rng.choice([180, 180, 180, 200, 230]))
+        q1 = rng.integers(20, 41, 50).astype(np.uint8).tobytes()
+        q2 = rng.integers(20, 41, 50).astype(np.uint8).tobytes()
+        mq = int(rng.integers(0, 61))
+        u = rng.random()
+        if u < 0.08:      # single-end read in a paired file
+            items.append((tid, p0, i, make_record(name, 0, tid, p0, mq, [("M", 50)], 50, q1)))
+        elif u < 0.13:    # mate unmapped
+            items.append((tid, p0, i, make_record(name, 0x1 | 0x8 | 0x40, tid, p0, mq, [("M", 50)],
+                                                  50, q1, mtid=tid, mpos=p0)))
+            items.append((tid, p0, i, make_record(name, 0x1 | 0x4 | 0x80, tid, p0, 0, [], 50, q2,
+                                                  mtid=tid, mpos=p0)))
+        elif u < 0.20:    # chimeric: mate on the other reference
+            mp = 500 + int(rng.integers(0, 1000))
+            items.append((tid, p0, i, make_record(name, 0x1 | 0x40 | 0x20, tid, p0, mq, [("M", 50)],
+                                                  50, q1, mtid=1 - tid, mpos=mp)))
+            items.append((1 - tid, mp, i, make_record(name, 0x1 | 0x80 | 0x10, 1 - tid, mp, mq,
+                                                      [("M", 50)], 50, q2, mtid=tid, mpos=p0)))
+        elif u < 0.22:    # unmapped, unpaired
+            items.append((tid, p0, i, make_record(name, 0x4, tid, p0, 0, [], 50, q1)))
+        else:             # proper pair, first mate forward
+            mp = p0 + tl - 50
+            items.append((tid, p0, i, make_record(name, 0x1 | 0x2 | 0x40 | 0x20, tid, p0, mq,
+                                                  [("M", 50)], 50, q1, mtid=tid, mpos=mp, tlen=tl)))
+            mate = make_record(name, 0x1 | 0x2 | 0x80 | 0x10, tid, mp, mq, [("M", 50)], 50, q2,
+                               mtid=tid, mpos=p0, tlen=-tl)
+            items.append((tid, mp, i, mate))
+            if u > 0.99:  # the same second mate twice: written once (:449-455)
+                items.append((tid, mp, i, mate))
+    items.sort(key=lambda t: (t[0], t[1], t[2]))
+    return make_header(refs), [t[3] for t in items]
 
 
 def synthetic_bam(seed, n_positions, reads_per_position, umi_len=12, err=0.02, extras=True):

@@ -70,6 +70,31 @@ def test_staging_matches_reference_restatement(tmp_path, merge, threads):
     assert got["nmask"].any() and len(got["bucket_off"]) > 121  # N bases, extra keys from strand/ref
 
 
+@pytest.mark.parametrize("flags,kw", [
+    ([], {}),
+    (["--remove-unpaired"], dict(remove_unpaired=True)),
+    (["--remove-chimeric", "--remove-unpaired"], dict(remove_chimeric=True, remove_unpaired=True)),
+])
+def test_paired_staging_matches_reference_restatement(tmp_path, flags, kw):
+    """--paired: second mates skipped, mate-unmapped pairs dropped, template length in the
+    alignment key (deduplicate_sam.rs:95-139)."""
+    header, recs = bamio.synthetic_paired_bam(11, 60, 40)
+    src, dump = str(tmp_path / "in.bam"), str(tmp_path / "stage.bin")
+    write_bam(src, header, recs)
+    r = run(["-i", src, "-o", str(tmp_path / "unused.bam"), "--paired", "--dump-staging", dump,
+             "--num-threads", "3"] + flags)
+    assert r.returncode == 0, r.stderr
+    got = read_staging(dump)
+    exp, _ = bamio.stage_like_reference(recs, merge="mapqual", paired=True, **kw)
+    single, _ = bamio.stage_like_reference(recs, merge="mapqual")
+    assert len(exp["bucket_off"]) != len(single["bucket_off"])  # the key really changed
+    for f in ("keys", "nmask", "freq", "bucket_off"):
+        assert (got[f] == exp[f]).all(), f
+    assert (got["rep"].astype(np.int64) == exp["rep"]).all()
+    # cli.rs / main.rs:23-25: --paired with --keep-unmapped is refused
+    assert run(["-i", src, "-o", str(tmp_path / "o.bam"), "--paired", "--keep-unmapped"]).returncode != 0
+
+
 def test_cli_error_behaviour(tmp_path):
     header, recs = bamio.synthetic_bam(3, 5, 10, extras=False)
     src = str(tmp_path / "in.bam")

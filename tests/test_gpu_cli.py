@@ -69,3 +69,39 @@ def test_deep_position_with_and_without_pruning(tmp_path):
     for data in ("naive", "ngrambktree"):
         oh, orecs, log = run_cli(tmp_path, header, recs, ["--data", data, "--num-threads", "4"])
         assert orecs == exp, data
+
+
+@pytest.mark.parametrize("extra,kw", [
+    ([], {}),
+    (["--remove-unpaired", "--remove-chimeric", "--merge", "avgqual"],
+     dict(remove_unpaired=True, remove_chimeric=True, merge="avgqual")),
+    (["--algo", "adj", "--num-threads", "4"], dict(algo="adj")),
+])
+def test_paired_end_mode(tmp_path, extra, kw):
+    """--paired end to end: first mates are deduplicated on (strand, position, reference,
+    template length), the second mates of the survivors are written when the reference changes
+    and at the end, in file order (UcWriter, deduplicate_sam.rs:382-459)."""
+    header, recs = bamio.synthetic_paired_bam(21, 120, 50)
+    kw.setdefault("merge", "mapqual")
+    oh, orecs, log = run_cli(tmp_path, header, recs, ["--paired"] + extra)
+    exp, st = bamio.expected_output(recs, paired=True, **kw)
+    assert oh == header
+    assert orecs == exp
+    n_second = sum(1 for r in orecs if bamio.parse_record(r)["flag"] & 0x80)
+    assert n_second > 100  # mates really travel
+    # an unsorted file: blocks of records in shuffled order, so the written records change
+    # reference many times and every change triggers a partial mate pass
+    import numpy as np
+    blocks = [recs[i:i + 300] for i in range(0, len(recs), 300)]
+    order = np.random.default_rng(3).permutation(len(blocks))
+    mixed = [r for b in order for r in blocks[b]]
+    oh, orecs, _ = run_cli(tmp_path, header, mixed, ["--paired"] + extra)
+    exp2, _ = bamio.expected_output(mixed, paired=True, **kw)
+    assert orecs == exp2
+    tids = [bamio.parse_record(r)["tid"] for r in orecs]
+    assert sum(1 for a, b in zip(tids, tids[1:]) if a != b) > 4
+    c = st["counters"]
+    assert "Number of input reads: %d" % c["total"] in log
+    assert "Number of removed unmapped reads: %d" % c["unmapped"] in log
+    assert "Number of unpaired reads: %d" % c["unpaired"] in log
+    assert "Number of chimeric reads: %d" % c["chimeric"] in log

@@ -43,6 +43,8 @@ struct Record {
     uint16_t flag() const { return rd_u16(body() + 14); }
     int32_t l_seq() const { return rd_i32(body() + 16); }
     int32_t mtid() const { return rd_i32(body() + 20); }
+    int32_t mpos() const { return rd_i32(body() + 24); }
+    int32_t tlen() const { return rd_i32(body() + 28); }
     const uint8_t *qname() const { return body() + 32; }
     size_t qname_len() const { return l_read_name() ? (size_t)l_read_name() - 1 : 0; } // without the NUL
     const uint8_t *cigar() const { return qname() + l_read_name(); }
@@ -52,6 +54,7 @@ struct Record {
     bool is_reverse() const { return flag() & 0x10; }
     bool is_paired() const { return flag() & 0x1; }
     bool is_last_in_template() const { return flag() & 0x80; }
+    bool is_mate_unmapped() const { return flag() & 0x8; }
 
     // utils::get_unclipped_pos (src/utils/mod.rs:96-104) over rust-htslib 0.49's
     // CigarStringView::{pos,end_pos,leading_*,trailing_*}.  That crate's source is not in the

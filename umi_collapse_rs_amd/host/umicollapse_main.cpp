@@ -4,8 +4,11 @@
 //
 // "Next" rows N1/N2 of SURVEY.md 8f.  Deterministic where the reference is not: buckets and
 // freq ties follow first appearance in the input (canonical determinisation).
-// Not implemented, as in / beyond the reference: --mode fastq and --tag (unfinished in the
-// reference: main.rs:49-50, deduplicate_sam.rs:236-239), --paired (N4), --two-pass, --algo cc.
+// --paired (N4): template length joins the alignment key, second mates are skipped while
+// staging and follow their surviving first mates into the output (UcWriter,
+// deduplicate_sam.rs:339-459).  Not implemented, as in / beyond the reference: --mode fastq and
+// --tag (unfinished in the reference: main.rs:49-50, deduplicate_sam.rs:236-239), --two-pass,
+// --algo cc.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -13,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/umihip.h"
@@ -56,7 +60,11 @@ void usage()
               "      --data <DATA>        every value gives Naive's result (as in the reference);\n"
               "                           naive = plain all-pairs, others = + exact range pruning\n"
               "      --keep-unmapped      Keep unmapped reads\n"
-              "      --two-pass --paired --remove-unpaired --remove-chimeric --tag   (see header)\n"
+              "      --paired             Paired-end mode: template length joins the alignment key,\n"
+              "                           second mates follow their surviving first mates\n"
+              "      --remove-unpaired    Remove unpaired reads (paired-end mode)\n"
+              "      --remove-chimeric    Remove chimeric pairs (paired-end mode)\n"
+              "      --two-pass --tag     accepted and rejected (see header)\n"
               "      --device <ID>        GPU to use [default: 0]");
 }
 
@@ -104,15 +112,31 @@ struct Entry { // one (alignment key, UMI): ReadFreq of src/utils/read_freq.rs +
     uint32_t bucket;
 };
 
+// Align (deduplicate_sam.rs:478-481): Alignment{strand, coord, ref} or, with --paired,
+// PairedAlignment{strand, coord, ref, tlen} (:547-553); ref as tid (equal names <=> equal tid)
+struct AlignKey {
+    uint64_t coord, ref_strand, tlen;
+    bool operator==(const AlignKey &o) const { return coord == o.coord && ref_strand == o.ref_strand && tlen == o.tlen; }
+};
+
 struct KeyHash {
-    size_t operator()(const std::pair<uint64_t, uint64_t> &k) const
+    size_t operator()(const AlignKey &k) const
     {
-        uint64_t x = k.first * 0x9E3779B97F4A7C15ull ^ (k.second + 0x7F4A7C15u);
+        uint64_t x = k.coord * 0x9E3779B97F4A7C15ull ^ (k.ref_strand + 0x7F4A7C15u) ^ (k.tlen * 0xD6E8FEB86659FD93ull);
         x ^= x >> 29;
         x *= 0xBF58476D1CE4E5B9ull;
         return (size_t)(x ^ (x >> 32));
     }
 };
+
+// ReverseRead (deduplicate_sam.rs:272-286): the mate a written paired record is waiting for
+std::string mate_key(const uint8_t *qname, size_t n, int32_t tid, int32_t pos)
+{
+    std::string s((const char *)qname, n);
+    s.append((const char *)&tid, 4);
+    s.append((const char *)&pos, 4);
+    return s;
+}
 
 // UcSAMRead::get_umi_length (read.rs:65-75,87-94): first separator followed by a base
 // (caseless [ATCGN]), length of that run.
@@ -146,7 +170,6 @@ int main(int argc, char **argv)
     if (args.paired && args.keep_unmapped) die("Cannot keep unmapped reads with paired-end reads!");
     if (args.mode == "fastq") die("fastq mode is not implemented (nor in the reference: main.rs:49-50)");
     if (args.mode != "bam" && args.mode != "sam") return 0; // main.rs:49-95: nothing happens
-    if (args.paired) die("--paired is not implemented in this build (SURVEY.md 8f N4)");
     if (args.track_clusters) die("--tag is not implemented (unfinished in the reference: deduplicate_sam.rs:236-239)");
     int algo, merge;
     if (args.algo == "dir") algo = UMI_ALGO_DIRECTIONAL;
@@ -172,16 +195,38 @@ int main(int argc, char **argv)
         const uint32_t n_rec = (uint32_t)in.records.size();
         const unsigned T = std::max(1u, args.num_threads);
         size_t umi_length = args.umi_length;
-        if (umi_length == 0 && !args.passthrough) // autodetect on the first mapped read (:154-156)
-            for (uint32_t ri = 0; ri < n_rec; ri++)
-                if (!in.records[ri].is_unmapped()) {
+        // the filters of the read loop (:95-129); returns ReadInfo::state
+        auto classify = [&](const umi::bam::Record &r, uint8_t &is_unpaired, uint8_t &is_chimeric) -> uint8_t {
+            is_unpaired = is_chimeric = 0;
+            if (args.paired && r.is_paired() && r.is_last_in_template()) return 3; // :95-97
+            if (r.is_unmapped()) return 1;                                         // :102-108
+            if (args.paired && !args.passthrough) {                                // :110-129
+                if (!r.is_paired()) {
+                    is_unpaired = 1;
+                    if (args.remove_unpaired) return 5;
+                }
+                if (r.is_paired() && r.is_mate_unmapped()) return 4;
+                if (r.is_paired() && r.tid() != r.mtid()) {
+                    is_chimeric = 1;
+                    if (args.remove_chimeric) return 5;
+                }
+            }
+            return 0;
+        };
+        if (umi_length == 0 && !args.passthrough) // autodetect on the first staged read (:154-156)
+            for (uint32_t ri = 0; ri < n_rec; ri++) {
+                uint8_t u, c;
+                if (classify(in.records[ri], u, c) == 0) {
                     umi_length = detect_umi_length(in.records[ri].qname(), in.records[ri].qname_len(), args.umi_sep);
                     break;
                 }
+            }
         struct ReadInfo {
-            uint64_t coord, ref_strand, key, nmask;
+            uint64_t coord, ref_strand, tlen, key, nmask;
             int32_t score;
-            uint8_t state; // 0 mapped, 1 unmapped, 2 error
+            uint8_t state; // 0 staged, 1 unmapped, 2 error, 3 second mate (not counted),
+                           // 4 mate unmapped, 5 filtered (--remove-unpaired / --remove-chimeric)
+            uint8_t unpaired, chimeric;
         };
         std::vector<ReadInfo> info(n_rec);
         std::vector<std::string> errors(T);
@@ -192,9 +237,10 @@ int main(int argc, char **argv)
             for (uint32_t ri = lo; ri < hi; ri++) {
                 const umi::bam::Record &r = in.records[ri];
                 ReadInfo &ii = info[ri];
-                if (r.is_unmapped()) { ii.state = 1; continue; } // :102-108
-                ii.state = 0;
-                if (args.passthrough) continue;
+                ii.tlen = 0;
+                ii.state = classify(r, ii.unpaired, ii.chimeric);
+                if (ii.state != 0 || args.passthrough) continue;
+                if (args.paired) ii.tlen = (uint64_t)(int64_t)r.tlen(); // record.insert_size(), :138
                 // Alignment{strand, coord, ref} (:141-145); equality on tid == equality on the name
                 ii.coord = (uint64_t)r.unclipped_pos();
                 ii.ref_strand = ((uint64_t)(uint32_t)r.tid() << 1) | (r.is_reverse() ? 1u : 0u);
@@ -218,9 +264,13 @@ int main(int argc, char **argv)
         for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
             if (first_error[t] != UINT32_MAX) die(errors[t]);
 
-        size_t total_read_count = n_rec, unmapped = 0;
+        size_t total_read_count = 0, unmapped = 0, unpaired = 0, chimeric = 0;
         std::vector<uint32_t> out_records; // records written before dedup (--keep-unmapped, :104-106)
         for (uint32_t ri = 0; ri < n_rec; ri++) {
+            if (info[ri].state != 3) total_read_count++; // :99
+            unpaired += info[ri].unpaired;
+            chimeric += info[ri].chimeric;
+            if (info[ri].state == 4) unmapped++; // :118-121
             if (info[ri].state == 1) {
                 unmapped++;
                 if (args.keep_unmapped || args.passthrough) out_records.push_back(ri);
@@ -230,7 +280,7 @@ int main(int argc, char **argv)
         }
 
         struct Shard {
-            std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> bucket_of; // Align -> local bucket
+            std::unordered_map<AlignKey, uint32_t, KeyHash> bucket_of; // Align -> local bucket
             std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // key -> local entry
             std::vector<std::vector<uint32_t>> bucket_entries;
             std::vector<uint32_t> bucket_first; // first read of the bucket
@@ -243,7 +293,7 @@ int main(int argc, char **argv)
             for (uint32_t ri = 0; ri < n_rec; ri++) {
                 const ReadInfo &ii = info[ri];
                 if (ii.state != 0) continue;
-                const std::pair<uint64_t, uint64_t> akey(ii.coord, ii.ref_strand);
+                const AlignKey akey{ii.coord, ii.ref_strand, ii.tlen};
                 if (hasher(akey) % T != t) continue;
                 auto it = sh.bucket_of.find(akey);
                 uint32_t b;
@@ -336,8 +386,54 @@ int main(int argc, char **argv)
             t_gpu1 = now_s();
             umi_ctx_destroy(ctx);
         }
-        for (size_t i = 0; i < n; i++)
-            if (kept[i]) out_records.push_back(rep[i]); // :227-231, in rank order per bucket
+        if (!args.paired) {
+            for (size_t i = 0; i < n; i++)
+                if (kept[i]) out_records.push_back(rep[i]); // :227-231, in rank order per bucket
+        } else {
+            // UcWriter (:382-459): every written paired record leaves (qname, mate ref, mate pos)
+            // in a set; when the reference name of the written records changes, and once at the
+            // end, the input is scanned again in file order and the second mates found in the set
+            // are written.  The file is in memory here, so the scans walk record indices (per
+            // reference for the partial passes).  The reference's set hashes the coordinate but
+            // compares only names (:288-296); here the coordinate is part of the identity.
+            std::unordered_map<int32_t, std::vector<uint32_t>> mates_on; // tid -> second mates, file order
+            std::vector<uint32_t> mates_all;
+            for (uint32_t ri = 0; ri < n_rec; ri++) {
+                const umi::bam::Record &r = in.records[ri];
+                if (!r.is_unmapped() && r.is_paired() && r.is_last_in_template() && !r.is_mate_unmapped()) { // :425-429
+                    mates_on[r.tid()].push_back(ri);
+                    mates_all.push_back(ri);
+                }
+            }
+            std::unordered_set<std::string> waiting;
+            auto write_reversed = [&](const std::vector<uint32_t> &cands) {
+                for (uint32_t ri : cands) {
+                    if (waiting.empty()) break;
+                    const umi::bam::Record &r = in.records[ri];
+                    auto it = waiting.find(mate_key(r.qname(), r.qname_len(), r.tid(), r.pos()));
+                    if (it != waiting.end()) {
+                        out_records.push_back(ri);
+                        waiting.erase(it);
+                    }
+                }
+            };
+            bool have_ref = false;
+            int32_t cur_ref = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (!kept[i]) continue;
+                const umi::bam::Record &r = in.records[rep[i]];
+                if (!have_ref) {
+                    have_ref = true;
+                } else if (cur_ref != r.tid()) {
+                    auto m = mates_on.find(cur_ref);
+                    if (m != mates_on.end()) write_reversed(m->second); // write_reversed(false), :390-393
+                }
+                cur_ref = r.tid();
+                if (r.is_paired()) waiting.insert(mate_key(r.qname(), r.qname_len(), r.mtid(), r.mpos())); // :395-401
+                out_records.push_back(rep[i]);
+            }
+            if (have_ref) write_reversed(mates_all); // close(), :411-415
+        }
 
         // ---- write: header verbatim (Header::from_template :357-362) + surviving records verbatim
         size_t out_len = in.header_len;
@@ -356,6 +452,10 @@ int main(int argc, char **argv)
         // counters of deduplicate_sam.rs:243-268
         std::fprintf(stderr, "Number of input reads: %zu\n", total_read_count);
         std::fprintf(stderr, "Number of removed unmapped reads: %zu\n", unmapped);
+        if (args.paired) {
+            std::fprintf(stderr, "Number of unpaired reads: %zu\n", unpaired);
+            std::fprintf(stderr, "Number of chimeric reads: %zu\n", chimeric);
+        }
         std::fprintf(stderr, "Number of unique alignment positions: %zu\n", nb);
         std::fprintf(stderr, "Number of UMIs: %zu\n", n);
         std::fprintf(stderr, "Average number of UMIs per alignment position: %g\n", nb ? (double)n / (double)nb : 0.0);
