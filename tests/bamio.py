@@ -172,6 +172,7 @@ def stage_like_reference(recs, merge="mapqual", umi_len=0, sep=95, keep_unmapped
     st["rep"] = np.array(rec_idx, dtype=np.int64)[st["rep"].astype(np.int64)] if len(rec_idx) else st["rep"]
     st["umi_len"] = umi_len
     st["counters"] = counters
+    st["reads"] = list(zip(rec_idx, bucket_ids, umis))  # staged reads in file order
     return st, pre
 
 
@@ -217,6 +218,35 @@ def expected_output(recs, k=1, p=0.5, algo="dir", **kw):
     if kw.get("paired"):
         out = paired_writer(recs, out)
     return [recs[i] for i in out], st
+
+
+def expected_tagged_output(recs, k=1, p=0.5, algo="dir", **kw):
+    """--tag as this build finishes it (the reference's second pass is a TODO,
+    deduplicate_sam.rs:236-239): every staged read, in file order, with MI:i = offset + index
+    of its cluster's root among the survivors (cluster_tracker.rs:88-100 with
+    deduplicate_sam.rs:215), cs:i = reads in the cluster (temp_freq, :83-85), su:i = reads with
+    the same UMI at the same position (ReadFreq.freq)."""
+    st, pre = stage_like_reference(recs, **kw)
+    kept, root, _ = orc.dedup_batch(st["keys"], st["nmask"], st["freq"], st["bucket_off"],
+                                    st["umi_len"], k, p, 0 if algo == "dir" else 1)
+    cluster_id = np.cumsum(kept) - 1
+    cluster_reads = np.zeros(len(kept), np.int64)
+    np.add.at(cluster_reads, root.astype(np.int64), st["freq"])
+    index = {}
+    off = st["bucket_off"].astype(np.int64)
+    for b in range(len(off) - 1):
+        for e in range(off[b], off[b + 1]):
+            index[(b, int(st["keys"][e]))] = e
+    out = [recs[i] for i in pre]
+    for ri, b, umi in st["reads"]:
+        key, _ = orc.encode_keys([umi.decode()])
+        e = index[(b, int(key[0]))]
+        r = int(root[e])
+        tags = b"".join(t + b"i" + struct.pack("<i", int(v)) for t, v in
+                        ((b"MI", cluster_id[r]), (b"cs", cluster_reads[r]), (b"su", st["freq"][e])))
+        body = recs[ri][4:] + tags
+        out.append(struct.pack("<i", len(body)) + body)
+    return out, st, int(kept.sum())
 
 
 def synthetic_paired_bam(seed, n_positions, pairs_per_position, umi_len=10, err=0.03):

@@ -105,3 +105,19 @@ def test_paired_end_mode(tmp_path, extra, kw):
     assert "Number of removed unmapped reads: %d" % c["unmapped"] in log
     assert "Number of unpaired reads: %d" % c["unpaired"] in log
     assert "Number of chimeric reads: %d" % c["chimeric"] in log
+
+
+@pytest.mark.parametrize("extra,kw", [
+    (["--num-threads", "5"], {}),
+    (["--algo", "adj", "--keep-unmapped"], dict(algo="adj", keep_unmapped=True)),
+    (["-k", "2", "--merge", "avgqual", "--data", "naive"], dict(k=2, merge="avgqual")),
+])
+def test_tag_mode_writes_every_read_with_its_cluster(tmp_path, extra, kw):
+    header, recs = bamio.synthetic_bam(9, 200, 40, umi_len=10, err=0.04)
+    kw.setdefault("merge", "mapqual")
+    oh, orecs, log = run_cli(tmp_path, header, recs, ["--tag"] + extra)
+    exp, st, groups = bamio.expected_tagged_output(recs, **kw)
+    assert oh == header
+    assert orecs == exp
+    assert "Number of groups of reads: %d" % groups in log
+    assert len(orecs) > groups or kw.get("algo") == "adj"

@@ -6,9 +6,14 @@
 // freq ties follow first appearance in the input (canonical determinisation).
 // --paired (N4): template length joins the alignment key, second mates are skipped while
 // staging and follow their surviving first mates into the output (UcWriter,
-// deduplicate_sam.rs:339-459).  Not implemented, as in / beyond the reference: --mode fastq and
-// --tag (unfinished in the reference: main.rs:49-50, deduplicate_sam.rs:236-239), --two-pass,
-// --algo cc.
+// deduplicate_sam.rs:339-459).
+// --tag (N3): the reference stops after collecting its ClusterTrackers (the second pass is a
+// TODO, deduplicate_sam.rs:236-239, so its output holds no deduplicated records at all).  Here
+// the pass is finished from what the trackers hold (cluster_tracker.rs:76-103): every staged
+// read is written, in file order, with MI:i = cluster id (offset + index of the cluster's root
+// among the survivors), cs:i = reads in the cluster, su:i = reads with the same UMI at the same
+// position.  Nothing in the reference to be in parity with: tests/bamio.py defines it.
+// Not implemented, as in the reference: --mode fastq (main.rs:49-50), --two-pass, --algo cc.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -64,7 +69,9 @@ void usage()
               "                           second mates follow their surviving first mates\n"
               "      --remove-unpaired    Remove unpaired reads (paired-end mode)\n"
               "      --remove-chimeric    Remove chimeric pairs (paired-end mode)\n"
-              "      --two-pass --tag     accepted and rejected (see header)\n"
+              "      --tag                Write every read tagged with its cluster (MI, cs, su) instead of\n"
+              "                           removing duplicates\n"
+              "      --two-pass           accepted and rejected (see header)\n"
               "      --device <ID>        GPU to use [default: 0]");
 }
 
@@ -170,7 +177,7 @@ int main(int argc, char **argv)
     if (args.paired && args.keep_unmapped) die("Cannot keep unmapped reads with paired-end reads!");
     if (args.mode == "fastq") die("fastq mode is not implemented (nor in the reference: main.rs:49-50)");
     if (args.mode != "bam" && args.mode != "sam") return 0; // main.rs:49-95: nothing happens
-    if (args.track_clusters) die("--tag is not implemented (unfinished in the reference: deduplicate_sam.rs:236-239)");
+    if (args.track_clusters && args.paired) die("--tag with --paired is not implemented (the reference never reaches its tagging pass)");
     int algo, merge;
     if (args.algo == "dir") algo = UMI_ALGO_DIRECTIONAL;
     else if (args.algo == "adj") algo = UMI_ALGO_ADJACENCY;
@@ -287,6 +294,7 @@ int main(int argc, char **argv)
             std::vector<Entry> entries;
         };
         std::vector<Shard> shards(args.passthrough ? 0 : T);
+        std::vector<uint32_t> entry_of(args.track_clusters ? n_rec : 0); // read -> entry of its shard (--tag)
         KeyHash hasher;
         umi::bgzf::parallel_for(shards.size(), T, [&](size_t t) {
             Shard &sh = shards[t];
@@ -308,6 +316,7 @@ int main(int argc, char **argv)
                 }
                 auto &idx = sh.umi_index[b];
                 auto e = idx.find(ii.key);
+                if (args.track_clusters) entry_of[ri] = e == idx.end() ? (uint32_t)sh.entries.size() : e->second;
                 if (e == idx.end()) { // Vacant :161-163
                     idx.emplace(ii.key, (uint32_t)sh.entries.size());
                     sh.bucket_entries[b].push_back((uint32_t)sh.entries.size());
@@ -340,12 +349,15 @@ int main(int argc, char **argv)
         std::vector<uint32_t> rep(n);
         bool any_n = false;
         size_t w = 0, max_umi = 0;
+        std::vector<std::vector<uint32_t>> global_of(args.track_clusters ? shards.size() : 0); // (shard, entry) -> index
+        for (size_t t = 0; t < global_of.size(); t++) global_of[t].resize(shards[t].entries.size());
         for (size_t b = 0; b < nb; b++) {
             Shard &sh = shards[order[b].shard];
             auto &v = sh.bucket_entries[order[b].local];
             std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return sh.entries[y].freq < sh.entries[x].freq; });
             for (uint32_t ei : v) {
                 const Entry &en = sh.entries[ei];
+                if (args.track_clusters) global_of[order[b].shard][ei] = (uint32_t)w;
                 keys[w] = en.key; nmask[w] = en.nmask; freq[w] = en.freq; rep[w] = en.rep;
                 any_n |= en.nmask != 0;
                 w++;
@@ -367,6 +379,7 @@ int main(int argc, char **argv)
 
         // ---- the hot path: one batched call replaces the bucket loop :207-233
         std::vector<uint8_t> kept(n + 1, 0);
+        std::vector<uint32_t> root(args.track_clusters ? n + 1 : 0);
         umi_stats st;
         std::memset(&st, 0, sizeof(st));
         double t_gpu0 = now_s(), t_gpu1 = t_gpu0;
@@ -381,12 +394,27 @@ int main(int argc, char **argv)
             t_gpu0 = now_s();
             if (umi_dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
                                 (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
-                                kept.data(), nullptr, &st) != UMI_OK)
+                                kept.data(), args.track_clusters ? root.data() : nullptr, &st) != UMI_OK)
                 die(umi_last_error());
             t_gpu1 = now_s();
             umi_ctx_destroy(ctx);
         }
-        if (!args.paired) {
+        // --tag: cluster id / size per entry from the root of every entry.  Survivors in index
+        // order are the roots in the order ClusterTracker::track sees them (bucket by bucket,
+        // rank order inside), so offset + idx (cluster_tracker.rs:88-100, deduplicate_sam.rs:215)
+        // is the running survivor count.
+        std::vector<uint32_t> cluster_id, cluster_reads;
+        std::vector<uint32_t> tagged; // staged reads in file order
+        if (args.track_clusters) {
+            cluster_id.assign(n, 0);
+            cluster_reads.assign(n, 0);
+            uint32_t next = 0;
+            for (size_t i = 0; i < n; i++)
+                if (kept[i]) cluster_id[i] = next++;
+            for (size_t i = 0; i < n; i++) cluster_reads[root[i]] += (uint32_t)freq[i]; // temp_freq, :83-85
+            for (uint32_t ri = 0; ri < n_rec; ri++)
+                if (info[ri].state == 0) tagged.push_back(ri);
+        } else if (!args.paired) {
             for (size_t i = 0; i < n; i++)
                 if (kept[i]) out_records.push_back(rep[i]); // :227-231, in rank order per bucket
         } else {
@@ -436,8 +464,10 @@ int main(int argc, char **argv)
         }
 
         // ---- write: header verbatim (Header::from_template :357-362) + surviving records verbatim
+        constexpr size_t TAG_BYTES = 3 * 7; // three int32 aux fields
         size_t out_len = in.header_len;
         for (uint32_t ri : out_records) out_len += (size_t)(in.records[ri].end - in.records[ri].begin);
+        for (uint32_t ri : tagged) out_len += (size_t)(in.records[ri].end - in.records[ri].begin) + TAG_BYTES;
         std::vector<uint8_t> out(out_len);
         std::memcpy(out.data(), in.data.data(), in.header_len);
         size_t o = in.header_len;
@@ -445,6 +475,25 @@ int main(int argc, char **argv)
             const size_t len = (size_t)(in.records[ri].end - in.records[ri].begin);
             std::memcpy(out.data() + o, in.records[ri].begin, len);
             o += len;
+        }
+        for (uint32_t ri : tagged) {
+            const size_t len = (size_t)(in.records[ri].end - in.records[ri].begin);
+            std::memcpy(out.data() + o, in.records[ri].begin, len);
+            const int32_t block_size = (int32_t)(len - 4 + TAG_BYTES);
+            std::memcpy(out.data() + o, &block_size, 4);
+            o += len;
+            const AlignKey akey{info[ri].coord, info[ri].ref_strand, info[ri].tlen};
+            const uint32_t e = global_of[hasher(akey) % T][entry_of[ri]];
+            const uint32_t r = root[e];
+            const struct { const char *tag; int32_t v; } aux[3] = {
+                {"MI", (int32_t)cluster_id[r]}, {"cs", (int32_t)cluster_reads[r]}, {"su", freq[e]}};
+            for (const auto &a : aux) {
+                out[o++] = (uint8_t)a.tag[0];
+                out[o++] = (uint8_t)a.tag[1];
+                out[o++] = 'i';
+                std::memcpy(out.data() + o, &a.v, 4);
+                o += 4;
+            }
         }
         umi::bgzf::compress_to_file(args.output, out.data(), out.size(), args.num_threads);
         const double t_end = now_s();
@@ -460,7 +509,8 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "Number of UMIs: %zu\n", n);
         std::fprintf(stderr, "Average number of UMIs per alignment position: %g\n", nb ? (double)n / (double)nb : 0.0);
         std::fprintf(stderr, "Max number of UMIs over all alignment positions: %zu\n", max_umi);
-        std::fprintf(stderr, "Number of reads after deduplicating: %llu\n", (unsigned long long)st.n_kept);
+        std::fprintf(stderr, args.track_clusters ? "Number of groups of reads: %llu\n" : "Number of reads after deduplicating: %llu\n",
+                     (unsigned long long)st.n_kept); // :259-266
         std::fprintf(stderr,
                      "phases: read+inflate %.3f s, staging %.3f s, hot path (H2D+GPU+D2H) %.3f s [%llu pairs], write %.3f s\n",
                      t_read - t_start, t_stage0 - t_read, t_gpu1 - t_gpu0, (unsigned long long)st.n_pairs, t_end - t_gpu1);
