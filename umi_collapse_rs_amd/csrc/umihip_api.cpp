@@ -73,13 +73,15 @@ struct DevBuf {
 
 struct Plan {
     std::vector<PairTask> small_tasks, big_tasks;
-    // bit-sliced tasks: [0] 64-thread tiles, [1] 256-thread tiles (diagonal tiles first)
-    std::vector<BsTask> bs_tasks[2];
+    // bit-sliced tasks: [0] column-split tiles, [1] wide tiles, [2]/[3] wide tiles of key-sorted
+    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run
+    std::vector<BsTask> bs_tasks[4];
     std::vector<PlaneTask> plane_tasks;
     struct BsBucket {
         uint64_t s, e, plane_off;
         uint32_t ngroups;
         bool wide;
+        int pu; // prefix units cached per column run (0: none; needs the bucket sorted by key)
     };
     std::vector<BsBucket> bs_buckets;
     uint64_t n_fused = 0; // buckets left to the fused one-wave kernel
@@ -87,7 +89,13 @@ struct Plan {
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0, n_tasks_pruned = 0;
     size_t n_bs() const
     {
-        return bs_tasks[0].size() + bs_tasks[1].size();
+        return bs_tasks[0].size() + bs_tasks[1].size() + bs_tasks[2].size() + bs_tasks[3].size();
+    }
+    bool any_sorted() const
+    {
+        for (auto &bb : bs_buckets)
+            if (bb.pu) return true;
+        return false;
     }
 };
 
@@ -108,6 +116,7 @@ struct umi_ctx {
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
+    bool bs_sorted = true; // sort large buckets by key and reuse prefix state along column runs
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
@@ -180,15 +189,30 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
                 }
                 BsTask t{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
                          (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
-                pl.bs_tasks[bb.wide ? 1 : 0].push_back(t);
+                pl.bs_tasks[!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1))].push_back(t);
                 pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
             }
         }
     }
 }
 
+// Prefix units worth caching for a key-sorted bucket of n entries: the state of the `pu`
+// highest 2-base units is reused along a run of columns that agree in them.  A run of random
+// keys is about n / 4^(bases that vary in the prefix) columns long; below ~4 columns the
+// bookkeeping costs more than it saves.
+int choose_prefix_units(uint64_t n, int umi_len)
+{
+    const int lp = bs_padded_len(umi_len), units = lp / 2, pad = lp - umi_len;
+    for (int pu = 4; pu >= 3; pu--) {
+        if (pu >= units) continue;
+        const int bases = std::max(0, 2 * pu - pad);
+        if ((n >> (2 * bases)) >= 4) return pu;
+    }
+    return 0;
+}
+
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, uint32_t fused_max, bool narrow_only, Plan &pl)
+                int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, Plan &pl)
 {
     pl.n_fused = 0;
     pl.small_tasks.clear();
@@ -221,7 +245,8 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             for (uint32_t g = 0; g < ngroups; g += 2)
                 pl.plane_tasks.push_back(
                     {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
-            pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide});
+            pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide,
+                                     wide && cache_prefix ? choose_prefix_units(n, umi_len) : 0});
             pl.plane_words += (uint64_t)np * ngroups;
         } else {
             for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
@@ -336,6 +361,7 @@ class Pipeline {
         if ((rc = upload_and_prep())) return rc;
         if ((rc = plan_and_upload_tasks())) return rc;
         if (prune && (rc = prune_stage())) return rc;
+        if (!prune && need_pairs && pl.any_sorted() && (rc = sort_stage())) return rc;
         if ((rc = upload_bitsliced())) return rc;
         if ((rc = pair_stage())) return rc;
         if (mode == MODE_NEIGHBOURS || n_parts > 1) return finish_neighbours();
@@ -394,15 +420,13 @@ class Pipeline {
     int plan_and_upload_tasks()
     {
         build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
-                   umi_len, fused_max, ctx->prune, pl);
+                   umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
         if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
         keep_my_share(pl.small_tasks);
         keep_my_share(pl.big_tasks);
-        if (!prune) {
-            keep_my_share(pl.bs_tasks[0]);
-            keep_my_share(pl.bs_tasks[1]);
-        }
+        if (!prune)
+            for (auto &v : pl.bs_tasks) keep_my_share(v);
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
         int rc;
@@ -488,8 +512,37 @@ class Pipeline {
             o += cnt;
         }
         gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
-        keep_my_share(pl.bs_tasks[0]);
-        keep_my_share(pl.bs_tasks[1]);
+        for (auto &v : pl.bs_tasks) keep_my_share(v);
+        bs_fkey = ctx->fkey_sorted.p;
+        bs_perm = ctx->perm.as<uint32_t>();
+        return UMI_OK;
+    }
+
+    // Buckets whose tiles reuse the counter state of the high units along runs of columns are
+    // sorted by filter key (the runs come from the order); the other large buckets keep their
+    // order behind an identity permutation, so that one pair of arrays serves every tile.
+    int sort_stage()
+    {
+        const size_t ksz = key32 ? 4 : 8;
+        size_t tmp_bytes = 0;
+        bool all = true;
+        for (auto &bb : pl.bs_buckets) {
+            if (bb.pu) tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
+            else all = false;
+        }
+        int rc;
+        if ((rc = ctx->fkey_sorted.reserve((size_t)n * ksz)) || (rc = ctx->perm.reserve((size_t)n * 4)) ||
+            (rc = ctx->iota.reserve((size_t)n * 4)) || (rc = ctx->sort_tmp.reserve(tmp_bytes)))
+            return rc;
+        if (!all) {
+            HIP_TRY(hipMemcpyAsync(ctx->fkey_sorted.p, ctx->fkey.p, (size_t)n * ksz, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(launch_iota(ctx->perm.as<uint32_t>(), n, s));
+        }
+        for (auto &bb : pl.bs_buckets)
+            if (bb.pu)
+                HIP_TRY(sort_bucket(ctx->fkey.p, key32, (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+                                    ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
+                                    ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
         return UMI_OK;
@@ -565,12 +618,14 @@ class Pipeline {
             PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
             b.fkey = bs_fkey;
             b.perm = bs_perm;
-            PairArgs w = b;
-            w.bs_tasks = b.bs_tasks + pl.bs_tasks[0].size();
-            HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[1].size(), true, key32, umi_len,
-                                    ctx->bs_unit, s));
-            HIP_TRY(launch_bs_pairs(b, (uint32_t)pl.bs_tasks[0].size(), false, key32, umi_len,
-                                    ctx->bs_unit, s));
+            size_t first = pl.bs_tasks[0].size() + pl.bs_tasks[1].size() + pl.bs_tasks[2].size();
+            for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
+                PairArgs w = b;
+                w.bs_tasks = b.bs_tasks + first;
+                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
+                                        ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
+                if (li > 0) first -= pl.bs_tasks[li - 1].size();
+            }
             PairArgs big = a;
             big.tasks = a.tasks + pl.small_tasks.size();
             HIP_TRY(launch_pairs(big, (uint32_t)pl.big_tasks.size(), true, key32, s));
@@ -865,6 +920,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "bs_unit")) {
         if (value < 1 || value > 3) return fail(UMI_ERR_ARG, "bs_unit must be 1, 2 or 3");
         ctx->bs_unit = (int)value;
+    } else if (!strcmp(name, "bs_sorted")) {
+        ctx->bs_sorted = value != 0;
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_max")) {

@@ -42,7 +42,7 @@ struct BsTask {
     uint32_t bucket_end;
     uint32_t group0;       // first 32-row group of this tile, relative to the bucket
     uint32_t ngroups;      // groups in the bucket = ceil(n / 32)
-    uint64_t plane_off;    // word offset of the bucket's planes: planes[plane_off + b*ngroups + g]
+    uint64_t plane_off;    // word offset of the bucket's planes: planes[plane_off + g*np + b] (group-major)
     uint32_t col0, col1;   // global column range
     uint32_t diag;         // 1 if some column index <= some row index (needs the row<col mask)
     uint32_t pad;
@@ -108,7 +108,7 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 // hold the same 64*G groups and split the columns
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
-                           int umi_len, int unit, hipStream_t s);
+                           int umi_len, int unit, int prefix_units, hipStream_t s);
 
 // ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
 size_t sort_temp_bytes(bool key32, uint32_t n);

@@ -15,6 +15,7 @@
 // 5-symbol distance only on the rare filter hits.  No MFMA (nothing here is a
 // dense contraction).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "umihip_internal.h"
 
@@ -333,30 +334,100 @@ __global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict
     const PlaneTask t = tasks[blockIdx.x];
     const uint32_t row = t.row0 + threadIdx.x;
     const KeyT key = row < t.bucket_end ? fkey[row] : (KeyT)0;
+    unsigned long long mine = 0; // lane b keeps plane b of the task's two row groups
     for (int b = 0; b < np; b++) {
         const unsigned long long bal = __ballot(bit_of(key, b));
-        if (threadIdx.x == 0) {
-            uint32_t *dst = planes + t.plane_off + (uint64_t)b * t.ngroups + t.group;
-            dst[0] = (uint32_t)bal;
-            if (t.group + 1 < t.ngroups) dst[1] = (uint32_t)(bal >> 32);
-        }
+        if ((int)threadIdx.x == b) mine = bal;
+    }
+    if ((int)threadIdx.x < np) { // group-major: a group's np plane words are contiguous
+        uint32_t *dst = planes + t.plane_off + (uint64_t)t.group * np + threadIdx.x;
+        dst[0] = (uint32_t)mine;
+        if (t.group + 1 < t.ngroups) dst[np] = (uint32_t)(mine >> 32);
     }
 }
 
 #define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
 constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
 
+// (any, two) = rows where at least one / at least two of the unit masks m(u), u in [U0, U1),
+// are set: units in triples give (any, two) with one or3 and one majority each, two groups
+// merge as two = twoA | twoB | (anyA & anyB).  6 ops for 6 units.
+template <int U0, int U1, class F>
+__device__ __forceinline__ void any_two_of_units(F m, uint32_t &any_acc, uint32_t &two_acc)
+{
+    any_acc = 0;
+    two_acc = 0;
+#pragma unroll
+    for (int u = U0; u < U1; u += 3) {
+        const int rem = U1 - u < 3 ? U1 - u : 3;
+        uint32_t any, two = 0;
+        if (rem == 3) {
+            const uint32_t ma = m(u), mb = m(u + 1), mc = m(u + 2);
+            any = BITOP3(ma, mb, mc, TT_A | TT_B | TT_C);
+            two = BITOP3(ma, mb, mc, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+        } else if (rem == 2) {
+            const uint32_t ma = m(u), mb = m(u + 1);
+            any = ma | mb;
+            two = ma & mb;
+        } else {
+            any = m(u);
+        }
+        if (u == U0) {
+            any_acc = any;
+            two_acc = two;
+        } else {
+            if (rem >= 2) two_acc |= BITOP3(two, any_acc, any, TT_A | (TT_B & TT_C));
+            else two_acc = BITOP3(two_acc, any_acc, any, TT_A | (TT_B & TT_C));
+            any_acc |= any; // dead (and dropped) when the caller only wants `two`
+        }
+    }
+}
+
+// sticky counters: s[l] |= rows with at least l set masks among m(u), u in [U0, U1); l = 1..K+1
+template <int K, int U0, int U1, class F>
+__device__ __forceinline__ void count_units(F m, uint32_t (&s)[K + 2])
+{
+#pragma unroll
+    for (int u = U0; u < U1; u += (K == 0 ? 2 : 1)) {
+        if (K == 0) { // "any unit differs": two units per op
+            if (u + 1 < U1) s[1] = BITOP3(s[1], m(u), m(u + 1), TT_A | TT_B | TT_C);
+            else s[1] |= m(u);
+        } else {
+            const uint32_t ma = m(u);
+#pragma unroll
+            for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
+            s[1] |= ma;
+        }
+    }
+}
+
 // COLSPLIT = false: the block's 4 waves hold 4 x 64 x G different row groups and all walk
 // every column (tiles of 8192*G rows, for very large buckets).  COLSPLIT = true: the 4 waves
 // hold the SAME 64 x G row groups and take every 4th column of the staged tile, so a bucket of
 // a few thousand entries still fills its lanes while the LDS staging is shared by 4 waves.
-template <typename KeyT, int LP, int G, int K, bool COLSPLIT, int GB>
+//
+// PU > 0 (keys of the bucket sorted, so neighbouring columns share their high bases): the
+// counter state after the PU highest units is kept per row group and recomputed only when a
+// column's high bases differ from its predecessor's (one flag bit per column, set while the
+// tile is staged); every column then costs its U - PU low units plus the merge.  Every pair is
+// still evaluated; what is shared is the part of the evaluation that is equal for both columns.
+template <typename KeyT, int LP, int G, int K, bool COLSPLIT, int GB, int PU>
 __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
 {
     constexpr int THREADS = 256;
     constexpr int NP = 2 * LP;
+    constexpr int U = LP / GB;    // units per key
+    constexpr int LIVE = U - PU;  // units evaluated for every column (the low ones)
     static_assert(LP % GB == 0 && NP % 4 == 0, "padded base count must be a multiple of the unit");
+    static_assert(PU == 0 || (GB == 2 && !COLSPLIT && PU < U), "prefix caching: 2-base units, wide tiles");
     __shared__ __attribute__((aligned(16))) uint32_t cmask[BS_COL_TILE * NP];
+    __shared__ uint32_t runbits[BS_COL_TILE / 32];
+    // filter hits of the current column tile: queued by the lane that finds them, checked
+    // exactly by all 256 threads once the tile's columns are done (a hit found inside the
+    // column loop would otherwise hold its whole wave for one serial verify per set bit)
+    constexpr uint32_t HITQ = 1024;
+    __shared__ uint2 hitq[HITQ];
+    __shared__ unsigned int hitq_count;
     __shared__ EdgeStage stage;
     const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x;
     const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(tp->bucket_start);
@@ -376,16 +447,30 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
     if (tid == 0) {
         stage.count = 0;
         stage.candidates = 0;
+        hitq_count = 0;
     }
 
     uint32_t p[G][NP];
     uint32_t valid[G];
     uint32_t rbase[G]; // bucket-relative index of the group's first row
+    uint32_t pre[G][K + 2]; // PU > 0: counter state after the prefix units ((any, two) for K = 1)
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int l = 0; l < K + 2; l++) pre[g][l] = 0u;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const uint32_t grp = COLSPLIT ? group0 + g * 64 + (tid & 63) : group0 + g * THREADS + tid;
+        // four planes per 128-bit load: they arrive, and stay, in an aligned register quad
 #pragma unroll
-        for (int b = 0; b < NP; b++) p[g][b] = grp < ngroups ? planes[(uint64_t)b * ngroups + grp] : 0u;
+        for (int q = 0; q < NP / 4; q++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (grp < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp * NP + 4 * q);
+            p[g][4 * q] = v.x;
+            p[g][4 * q + 1] = v.y;
+            p[g][4 * q + 2] = v.z;
+            p[g][4 * q + 3] = v.w;
+        }
         rbase[g] = grp * 32;
         valid[g] = rbase[g] >= n_rows ? 0u
                    : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
@@ -394,123 +479,208 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
     for (uint32_t c0 = col0; c0 < col1; c0 += BS_COL_TILE) {
         const uint32_t nc = min((uint32_t)BS_COL_TILE, col1 - c0);
         __syncthreads();
-        for (uint32_t w = tid; w < nc * NP; w += THREADS) {
-            const uint32_t c = w / NP, b = w % NP;
-            cmask[w] = bit_of(fkey[c0 + c], (int)b) ? 0xFFFFFFFFu : 0u;
+        // stage the tile: thread -> (column, quad of planes); the keys of a thread's columns are
+        // loaded together, each quad is one 128-bit LDS write.  Word j of quad q holds the mask
+        // of plane 4q + (j ^ 1): see unit_mask.
+        {
+            constexpr int QPC = NP / 4; // quads per column
+            constexpr int ITEMS = (BS_COL_TILE * QPC + THREADS - 1) / THREADS;
+            KeyT ck[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const uint32_t w = (uint32_t)tid + (uint32_t)it * THREADS;
+                const uint32_t c = w / QPC;
+                ck[it] = c < nc ? fkey[c0 + c] : (KeyT)0;
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const uint32_t w = (uint32_t)tid + (uint32_t)it * THREADS;
+                const uint32_t c = w / QPC, q = w % QPC;
+                if (c < nc) {
+                    uint4 v;
+                    v.x = bit_of(ck[it], (int)(4 * q + 1)) ? 0xFFFFFFFFu : 0u;
+                    v.y = bit_of(ck[it], (int)(4 * q)) ? 0xFFFFFFFFu : 0u;
+                    v.z = bit_of(ck[it], (int)(4 * q + 3)) ? 0xFFFFFFFFu : 0u;
+                    v.w = bit_of(ck[it], (int)(4 * q + 2)) ? 0xFFFFFFFFu : 0u;
+                    *reinterpret_cast<uint4 *>(&cmask[c * NP + 4 * q]) = v;
+                }
+            }
+        }
+        if (PU > 0 && tid < BS_COL_TILE) { // waves 0 and 1: one flag per column of the tile
+            bool newrun = false;
+            if ((uint32_t)tid < nc) {
+                newrun = (tid & 31) == 0; // the flags are consumed in words of 32 columns
+                if (!newrun) {
+                    constexpr int shift = (sizeof(KeyT) == 4 ? 2 : 3) * GB * LIVE; // bits below the prefix
+                    newrun = ((fkey[c0 + tid] ^ fkey[c0 + tid - 1]) >> shift) != 0;
+                }
+            }
+            const unsigned long long bal = __ballot(newrun);
+            if ((tid & 63) == 0) {
+                runbits[2 * (tid >> 6)] = (uint32_t)bal;
+                runbits[2 * (tid >> 6) + 1] = (uint32_t)(bal >> 32);
+            }
         }
         __syncthreads();
-        // hit masks of one column: h[g] = rows of group g within the filter's reach
-        auto column_hits = [&](uint32_t c, uint32_t (&h)[G]) -> uint32_t {
-            uint32_t cm[NP];
+
+        // The walk over the tile's columns, compiled twice: tiles on the bucket's diagonal mask
+        // every hit word with "row < column", the others do not carry that code at all.
+        auto walk_columns = [&](auto diag_tag) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
+            constexpr int LQ = PU > 0 ? LIVE : NP / 4; // quads of the units evaluated per column
+            // columns per group: one "does a run start here?" test and one "any hit?" test per
+            // group (both are VALU->scalar round trips or scalar branches: a wave issues one
+            // instruction per 4 cycles, so every one of them costs as much as a bitop3)
+            constexpr int NCOL = COLSPLIT ? 2 : (LQ <= 2 ? 4 : 2);
+            constexpr bool PRELOAD = LQ <= 2; // all masks of a group are fetched up front
+            constexpr uint32_t CSTEP = COLSPLIT ? 4u : 1u;
+
+            auto load_quads = [&](uint32_t c, int q0, int q1, uint32_t (&cm)[NP]) {
 #pragma unroll
-            for (int q = 0; q < NP / 4; q++)
-                *reinterpret_cast<uint4 *>(&cm[4 * q]) =
-                    *reinterpret_cast<const uint4 *>(&cmask[c * NP + 4 * q]);
-            uint32_t anyhit = 0;
+                for (int q = q0; q < q1; q++)
+                    *reinterpret_cast<uint4 *>(&cm[4 * q]) =
+                        *reinterpret_cast<const uint4 *>(&cmask[c * NP + 4 * q]);
+            };
+            // mismatch mask of a unit of GB consecutive bases (any of its 2*GB code bits
+            // differs): "P ^ c", then one bitop3 "acc | (P ^ c)" per further plane.
+            // gfx950 issues a VOP3 at half rate when its three source registers all have the
+            // same parity (tools/bankprobe.hip).  Planes and masks both sit in aligned
+            // register quads (128-bit loads), and the mask of plane b is word b ^ 1 of its
+            // quad, so P and c always differ in parity, whatever register holds acc; the
+            // leading xor is a bitop3 too (a VOP2 xor of mixed parity issues slower).
+            auto unit_mask = [&](const uint32_t (&cm)[NP], int g, int u) -> uint32_t {
+                uint32_t m = BITOP3(p[g][2 * GB * u], cm[(2 * GB * u) ^ 1], cm[(2 * GB * u) ^ 1], TT_A ^ TT_B);
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                uint32_t s[K + 2]; // s[l] = rows with at least l mismatches so far (l = 1..K+1)
+                for (int b = 1; b < 2 * GB; b++)
+                    m = BITOP3(m, p[g][2 * GB * u + b], cm[(2 * GB * u + b) ^ 1], TT_A | (TT_B ^ TT_C));
+                return m;
+            };
+            // a column whose high bases differ from its predecessor's: new prefix state
+            auto update_prefix = [&](uint32_t c) {
+                uint32_t cm[NP];
+                load_quads(c, LIVE, U, cm);
 #pragma unroll
-                for (int l = 0; l < K + 2; l++) s[l] = 0;
-                // mismatch mask of a unit of GB consecutive bases (any of its 2*GB code bits
-                // differs): one xor, then one bitop3 "acc | (P ^ c)" per further plane
-                auto unit_mask = [&](int u) -> uint32_t {
-                    uint32_t m = p[g][2 * GB * u] ^ cm[2 * GB * u];
+                for (int g = 0; g < G; g++) {
+                    auto unit = [&](int u) { return unit_mask(cm, g, u); };
+                    if (K == 1) {
+                        any_two_of_units<LIVE, U>(unit, pre[g][0], pre[g][1]);
+                    } else {
+                        uint32_t s[K + 2];
 #pragma unroll
-                    for (int b = 1; b < 2 * GB; b++)
-                        m = BITOP3(m, p[g][2 * GB * u + b], cm[2 * GB * u + b], TT_A | (TT_B ^ TT_C));
-                    return m;
-                };
-                constexpr int U = LP / GB; // units per key
-                if (K == 1) {
-                    // ">= 2 mismatching units" as a tree: units in triples give (any, two) with
-                    // one or3 and one majority each; two groups merge as
-                    // two = twoA | twoB | (anyA & anyB).  6 ops for the 6 units of L' = 12.
-                    uint32_t any_acc = 0, two_acc = 0;
+                        for (int l = 0; l < K + 2; l++) s[l] = 0;
+                        count_units<K, LIVE, U>(unit, s);
 #pragma unroll
-                    for (int u = 0; u < U; u += 3) {
-                        const int rem = U - u < 3 ? U - u : 3;
-                        const bool last = u + 3 >= U;
-                        uint32_t any, two = 0;
-                        if (rem == 3) {
-                            const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1), mc = unit_mask(u + 2);
-                            any = BITOP3(ma, mb, mc, TT_A | TT_B | TT_C);
-                            two = BITOP3(ma, mb, mc, (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
-                        } else if (rem == 2) {
-                            const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
-                            any = ma | mb;
-                            two = ma & mb;
-                        } else {
-                            any = unit_mask(u);
-                        }
-                        if (u == 0) {
-                            any_acc = any;
-                            two_acc = two;
-                        } else {
-                            if (rem >= 2) two_acc |= BITOP3(two, any_acc, any, TT_A | (TT_B & TT_C));
-                            else two_acc = BITOP3(two_acc, any_acc, any, TT_A | (TT_B & TT_C));
-                            if (!last) any_acc |= any;
-                        }
-                    }
-                    s[2] = two_acc;
-                } else {
-#pragma unroll
-                    for (int u = 0; u + 1 < U; u += 2) {
-                        const uint32_t ma = unit_mask(u), mb = unit_mask(u + 1);
-                        if (K == 0) {
-                            s[1] = BITOP3(s[1], ma, mb, TT_A | TT_B | TT_C);
-                        } else {
-#pragma unroll
-                            for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
-                            s[1] |= ma;
-#pragma unroll
-                            for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], mb, TT_A | (TT_B & TT_C));
-                            s[1] |= mb;
-                        }
-                    }
-                    if (U % 2) { // odd unit count: the last unit alone
-                        const uint32_t ma = unit_mask(U - 1);
-#pragma unroll
-                        for (int l = K + 1; l >= 2; l--) s[l] = BITOP3(s[l], s[l - 1], ma, TT_A | (TT_B & TT_C));
-                        s[1] |= ma;
+                        for (int l = 0; l < K + 2; l++) pre[g][l] = s[l];
                     }
                 }
-                uint32_t hg = ~s[K + 1] & valid[g];
-                if (diag) { // only rows before the column: keeps the self pair and i > j out
-                    const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
-                    const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
-                    hg &= lt;
+            };
+            // hit masks of one column from its live units (cm[0 .. 4 LQ)) and the prefix state:
+            // h[g] = rows of group g within the filter's reach
+            auto eval_column = [&](uint32_t c, const uint32_t (&cm)[NP], uint32_t (&h)[G]) -> uint32_t {
+                uint32_t anyhit = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    auto unit = [&](int u) { return unit_mask(cm, g, u); };
+                    uint32_t hg; // rows with at most K mismatching units
+                    if (K == 1) {
+                        uint32_t any, two;
+                        if (PU == 0) {
+                            any_two_of_units<0, U>(unit, any, two);
+                            hg = ~two & valid[g];
+                        } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
+                            const uint32_t t = BITOP3(pre[g][0], unit(0), unit(1),
+                                                      (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                        } else {
+                            any_two_of_units<0, LIVE>(unit, any, two);
+                            const uint32_t t = BITOP3(two, pre[g][0], any, TT_A | (TT_B & TT_C));
+                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                        }
+                    } else {
+                        uint32_t s[K + 2]; // s[l] = rows with at least l mismatching units (l = 1..K+1)
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) s[l] = PU > 0 ? pre[g][l] : 0u;
+                        count_units<K, 0, (PU > 0 ? LIVE : U)>(unit, s);
+                        hg = ~s[K + 1] & valid[g];
+                    }
+                    if (DIAG) { // only rows before the column: keeps the self pair and i > j out
+                        const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
+                        const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
+                        hg &= lt;
+                    }
+                    h[g] = hg;
+                    anyhit |= hg;
                 }
-                h[g] = hg;
-                anyhit |= hg;
+                return anyhit;
+            };
+            auto queue_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    uint32_t hh = h[g];
+                    while (hh) {
+                        const int j = __builtin_ctz(hh);
+                        hh &= hh - 1;
+                        const uint32_t row = bucket_start + rbase[g] + j;
+                        const unsigned int slot = atomicAdd(&hitq_count, 1u);
+                        if (slot < HITQ)
+                            hitq[slot] = make_uint2(row, c0 + c);
+                        else // queue full (a very dense tile): check it here and now
+                            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
+                                        &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
+                                        row, c0 + c, a.perm);
+                    }
+                }
+            };
+
+            constexpr uint32_t CBLK = PU > 0 ? 32u : (uint32_t)BS_COL_TILE; // columns per flag word
+            for (uint32_t cb = 0; cb < nc; cb += CBLK) {
+                const uint32_t runs = PU > 0 ? __builtin_amdgcn_readfirstlane(runbits[cb >> 5]) : 0u;
+                const uint32_t ce = min(nc, cb + CBLK);
+                uint32_t c = cb + (COLSPLIT ? (uint32_t)(tid >> 6) : 0u);
+                for (; c + (NCOL - 1) * CSTEP < ce; c += NCOL * CSTEP) { // whole groups
+                    uint32_t h[NCOL][G];
+                    uint32_t cm[NCOL][NP];
+                    uint32_t anyhit = 0;
+                    const uint32_t starts = PU > 0 ? (runs >> (c & 31)) & ((1u << NCOL) - 1u) : 0u;
+                    if (PRELOAD && starts == 0) { // the common case: straight-line code
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) load_quads(c + i * CSTEP, 0, LQ, cm[i]);
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i * CSTEP, cm[i], h[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) {
+                            if (PU > 0 && ((starts >> i) & 1u)) update_prefix(c + i * CSTEP);
+                            load_quads(c + i * CSTEP, 0, LQ, cm[i]);
+                            anyhit |= eval_column(c + i * CSTEP, cm[i], h[i]);
+                        }
+                    }
+                    if (__any(anyhit != 0)) {
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) queue_hits(c + i * CSTEP, h[i]);
+                    }
+                }
+                for (; c < ce; c += CSTEP) { // the columns that do not fill a group
+                    uint32_t h[G];
+                    uint32_t cm[NP];
+                    if (PU > 0 && ((runs >> (c & 31)) & 1u)) update_prefix(c);
+                    load_quads(c, 0, LQ, cm);
+                    if (__any(eval_column(c, cm, h) != 0)) queue_hits(c, h);
+                }
             }
-            return anyhit;
         };
-        auto emit_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                uint32_t hh = h[g];
-                while (hh) {
-                    const int j = __builtin_ctz(hh);
-                    hh &= hh - 1;
-                    verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
-                                &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
-                                bucket_start + rbase[g] + j, c0 + c, a.perm);
-                }
-            }
-        };
-        // two columns per "any hit?" test: the test costs a VALU->scalar round trip per wave
-        constexpr uint32_t CSTEP = COLSPLIT ? 4u : 1u;
-        for (uint32_t c = COLSPLIT ? (uint32_t)(tid >> 6) : 0u; c < nc; c += 2 * CSTEP) {
-            uint32_t h0[G], h1[G];
-            uint32_t anyhit = column_hits(c, h0);
-            const bool second = c + CSTEP < nc; // wave-uniform
-            if (second) anyhit |= column_hits(c + CSTEP, h1);
-            if (__any(anyhit != 0)) {
-                emit_hits(c, h0);
-                if (second) emit_hits(c + CSTEP, h1);
-            }
-        }
+        if (diag) walk_columns(std::true_type{});
+        else walk_columns(std::false_type{});
+
+        // exact check of the tile's filter hits, one per thread
+        __syncthreads();
+        const uint32_t nq = min(hitq_count, HITQ);
+        for (uint32_t i = tid; i < nq; i += THREADS)
+            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x, hitq[i].y,
+                        a.perm);
+        __syncthreads();
+        if (tid == 0) hitq_count = 0;
         flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
                              c0 + BS_COL_TILE >= col1);
     }
@@ -1100,45 +1270,50 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 
 namespace {
 template <typename KeyT, int LP, int G, int K>
-void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, hipStream_t s)
+void launch_bs_k(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int pu, hipStream_t s)
 {
     // unit = bases per counted unit: 2 by default (filter = "at most K units differ", a
     // superset of distance <= K that verify_pair makes exact), 1 = exact base count,
-    // 3 = fewer ops but 7x the false candidates on random 12-mers (k = 1, L' % 3 == 0 only)
+    // 3 = fewer ops but 7x the false candidates on random 12-mers (k = 1, L' % 3 == 0 only).
+    // pu = prefix units kept per run of columns (wide tiles of key-sorted buckets, unit 2)
     if (unit == 1) {
-        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 1><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, LP, G, K, true, 1><<<n_tasks, 256, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 1, 0><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, true, 1, 0><<<n_tasks, 256, 0, s>>>(a);
     } else if (unit == 3 && LP % 3 == 0 && K == 1) {
-        if (wide) bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, false, 3><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, true, 3><<<n_tasks, 256, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, false, 3, 0><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, (LP % 3 == 0 ? LP : 12), G, K, true, 3, 0><<<n_tasks, 256, 0, s>>>(a);
+    } else if (wide && pu == 3) {
+        bs_pair_kernel<KeyT, LP, G, K, false, 2, 3><<<n_tasks, 256, 0, s>>>(a);
+    } else if (wide && pu == 4 && LP / 2 > 4) {
+        bs_pair_kernel<KeyT, LP, G, K, false, 2, (LP / 2 > 4 ? 4 : 3)><<<n_tasks, 256, 0, s>>>(a);
     } else {
-        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 2><<<n_tasks, 256, 0, s>>>(a);
-        else bs_pair_kernel<KeyT, LP, G, K, true, 2><<<n_tasks, 256, 0, s>>>(a);
+        if (wide) bs_pair_kernel<KeyT, LP, G, K, false, 2, 0><<<n_tasks, 256, 0, s>>>(a);
+        else bs_pair_kernel<KeyT, LP, G, K, true, 2, 0><<<n_tasks, 256, 0, s>>>(a);
     }
 }
 template <typename KeyT, int LP, int G>
-void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, hipStream_t s)
+void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int pu, hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_tasks, wide, unit, s); break;
-    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_tasks, wide, unit, s); break;
-    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_tasks, wide, unit, s); break;
-    default: launch_bs_k<KeyT, LP, G, 3>(a, n_tasks, wide, unit, s); break;
+    case 0: launch_bs_k<KeyT, LP, G, 0>(a, n_tasks, wide, unit, pu, s); break;
+    case 1: launch_bs_k<KeyT, LP, G, 1>(a, n_tasks, wide, unit, pu, s); break;
+    case 2: launch_bs_k<KeyT, LP, G, 2>(a, n_tasks, wide, unit, pu, s); break;
+    default: launch_bs_k<KeyT, LP, G, 3>(a, n_tasks, wide, unit, pu, s); break;
     }
 }
 } // namespace
 
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
-                           int umi_len, int unit, hipStream_t s)
+                           int umi_len, int unit, int pu, hipStream_t s)
 {
     if (n_tasks == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
     if (key32) {
-        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_tasks, wide, unit, s);
-        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_tasks, wide, unit, s);
-        else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, unit, s);
+        if (lp == 8) launch_bs_lp<uint32_t, 8, 2>(a, n_tasks, wide, unit, pu, s);
+        else if (lp == 12) launch_bs_lp<uint32_t, 12, 2>(a, n_tasks, wide, unit, pu, s);
+        else launch_bs_lp<uint32_t, 16, 2>(a, n_tasks, wide, unit, pu, s);
     } else {
-        launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, unit, s);
+        launch_bs_lp<uint64_t, 22, 1>(a, n_tasks, wide, unit, pu, s);
     }
     return hipGetLastError();
 }
