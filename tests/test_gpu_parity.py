@@ -239,6 +239,47 @@ def test_large_single_bucket_both_kernels(ctx):
         c.close()
 
 
+def _wide_bucket(rng, n_raw, L, n_frac=0.0):
+    raw = rng.integers(0, 4, (n_raw, L))
+    if n_frac:
+        raw = np.where(rng.random(raw.shape) < n_frac, 4, raw)
+    umis = sorted({"".join("ACGTN"[c] for c in r) for r in raw})
+    rng.shuffle(umis)
+    freq = np.minimum(rng.geometric(0.5, len(umis)), 40).tolist()
+    umis, freq, _ = canonical(umis, freq)
+    keys, nm = orc.encode_keys(umis)
+    return keys, nm, np.array(freq, np.int32), np.array([0, len(umis)], np.uint64)
+
+
+@pytest.mark.parametrize("L,k,n_raw,n_frac,algo,amf", [
+    (10, 1, 42000, 0.0, 0, 0),    # 32-bit keys, table kernel (2 live units + cached prefix)
+    (9, 2, 40000, 0.002, 0, 0),   # the same with N bases and k = 2
+    (8, 0, 60000, 0.0, 0, 0),     # LP = 8: two prefix units only
+    (10, 1, 40000, 0.0, 1, 2),    # adjacency with a real max_freq
+    (12, 1, 36000, 0.0, 0, 0),    # too few entries per 8-base prefix: mask kernel, 3 cached units
+    (18, 2, 34000, 0.001, 0, 0),  # 64-bit keys: mask kernel with cached prefix, one group per lane
+    (14, 3, 34000, 0.0, 0, 0),    # LP = 16
+])
+def test_wide_sorted_buckets(L, k, n_raw, n_frac, algo, amf):
+    """Buckets of >= 32768 entries: sorted by filter key on the device; the table kernel or the
+    mask kernel with cached prefix state, checked against the oracle and against the same
+    context with sorting / tables switched off (identical edges, not only identical output)."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(1000 * L + k)
+    keys, nm, fr, off = _wide_bucket(rng, n_raw, L, n_frac)
+    assert len(keys) >= 32768
+    c = umi.Context(0)
+    try:
+        st = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
+        c.set_option("bs_tables", 0)
+        st1 = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
+        c.set_option("bs_sorted", 0)
+        st0 = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
+        assert st["n_edges"] == st1["n_edges"] == st0["n_edges"]
+    finally:
+        c.close()
+
+
 def test_edge_list_overflow_is_transparent():
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)

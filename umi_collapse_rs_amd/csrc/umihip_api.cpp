@@ -74,14 +74,16 @@ struct DevBuf {
 struct Plan {
     std::vector<PairTask> small_tasks, big_tasks;
     // bit-sliced tasks: [0] column-split tiles, [1] wide tiles, [2]/[3] wide tiles of key-sorted
-    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run
-    std::vector<BsTask> bs_tasks[4];
+    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run,
+    // [4] table-variant tiles (key-sorted, 32-bit keys, 2 live units)
+    std::vector<BsTask> bs_tasks[5];
     std::vector<PlaneTask> plane_tasks;
     struct BsBucket {
         uint64_t s, e, plane_off;
         uint32_t ngroups;
         bool wide;
-        int pu; // prefix units cached per column run (0: none; needs the bucket sorted by key)
+        int pu;   // prefix units cached per column run (0: none; needs the bucket sorted by key)
+        int live; // table variant: units looked up per column (0: not the table variant)
     };
     std::vector<BsBucket> bs_buckets;
     uint64_t n_fused = 0; // buckets left to the fused one-wave kernel
@@ -89,12 +91,14 @@ struct Plan {
     uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0, n_tasks_pruned = 0;
     size_t n_bs() const
     {
-        return bs_tasks[0].size() + bs_tasks[1].size() + bs_tasks[2].size() + bs_tasks[3].size();
+        size_t t = 0;
+        for (auto &v : bs_tasks) t += v.size();
+        return t;
     }
     bool any_sorted() const
     {
         for (auto &bb : bs_buckets)
-            if (bb.pu) return true;
+            if (bb.pu || bb.live) return true;
         return false;
     }
 };
@@ -117,6 +121,7 @@ struct umi_ctx {
     bool fused_sliced = true;
     int bs_unit = 2;
     bool bs_sorted = true; // sort large buckets by key and reuse prefix state along column runs
+    bool bs_tables = true; // ... and look the low units up in per-lane register tables (32-bit keys)
     // workspace
     DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
@@ -167,7 +172,7 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
     for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
         const Plan::BsBucket &bb = pl.bs_buckets[bi];
         const uint64_t s = bb.s, e = bb.e;
-        const uint32_t tile_groups = (bb.wide ? 256u : 64u) * gpl;
+        const uint32_t tile_groups = bb.live ? 256u * (uint32_t)BS_TAB_G2 : (bb.wide ? 256u : 64u) * gpl;
         const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
         auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
         auto key_hi = [&](uint64_t end) { // an upper bound of the last key of [.., end)
@@ -189,7 +194,8 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
                 }
                 BsTask t{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
                          (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
-                pl.bs_tasks[!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1))].push_back(t);
+                pl.bs_tasks[bb.live ? 4 : (!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1)))]
+                    .push_back(t);
                 pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
             }
         }
@@ -211,8 +217,19 @@ int choose_prefix_units(uint64_t n, int umi_len)
     return 0;
 }
 
+// Table variant (32-bit keys): two live units, if the prefix above them (the other units' bases,
+// less the padding) still gives runs of ~4 columns; 0 otherwise.
+int choose_live_units(uint64_t n, int umi_len)
+{
+    const int lp = bs_padded_len(umi_len), units = lp / 2, pad = lp - umi_len;
+    if (units <= 2) return 0;
+    const int bases = std::max(0, 2 * (units - 2) - pad);
+    return (n >> (2 * bases)) >= 4 ? 2 : 0;
+}
+
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, Plan &pl)
+                int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, bool tables,
+                Plan &pl)
 {
     pl.n_fused = 0;
     pl.small_tasks.clear();
@@ -245,8 +262,9 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             for (uint32_t g = 0; g < ngroups; g += 2)
                 pl.plane_tasks.push_back(
                     {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
+            const int live = wide && cache_prefix && tables ? choose_live_units(n, umi_len) : 0;
             pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide,
-                                     wide && cache_prefix ? choose_prefix_units(n, umi_len) : 0});
+                                     wide && cache_prefix && !live ? choose_prefix_units(n, umi_len) : 0, live});
             pl.plane_words += (uint64_t)np * ngroups;
         } else {
             for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
@@ -420,7 +438,8 @@ class Pipeline {
     int plan_and_upload_tasks()
     {
         build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
-                   umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs, pl);
+                   umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
+                   ctx->bs_tables && key32, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
         if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
         keep_my_share(pl.small_tasks);
@@ -527,11 +546,12 @@ class Pipeline {
         size_t tmp_bytes = 0;
         bool all = true;
         for (auto &bb : pl.bs_buckets) {
-            if (bb.pu) tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
+            if (bb.pu || bb.live) tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
             else all = false;
         }
         int rc;
-        if ((rc = ctx->fkey_sorted.reserve((size_t)n * ksz)) || (rc = ctx->perm.reserve((size_t)n * 4)) ||
+        // + 64 B: the table kernel reads column keys a group ahead of the chunk it works on
+        if ((rc = ctx->fkey_sorted.reserve((size_t)n * ksz + 64)) || (rc = ctx->perm.reserve((size_t)n * 4)) ||
             (rc = ctx->iota.reserve((size_t)n * 4)) || (rc = ctx->sort_tmp.reserve(tmp_bytes)))
             return rc;
         if (!all) {
@@ -539,7 +559,7 @@ class Pipeline {
             HIP_TRY(launch_iota(ctx->perm.as<uint32_t>(), n, s));
         }
         for (auto &bb : pl.bs_buckets)
-            if (bb.pu)
+            if (bb.pu || bb.live)
                 HIP_TRY(sort_bucket(ctx->fkey.p, key32, (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                     ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                     ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
@@ -618,13 +638,16 @@ class Pipeline {
             PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
             b.fkey = bs_fkey;
             b.perm = bs_perm;
-            size_t first = pl.bs_tasks[0].size() + pl.bs_tasks[1].size() + pl.bs_tasks[2].size();
-            for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
+            size_t first = pl.n_bs();
+            for (int li = 4; li >= 0; li--) { // lists sit in the device array in index order
+                first -= pl.bs_tasks[li].size();
                 PairArgs w = b;
                 w.bs_tasks = b.bs_tasks + first;
-                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
-                                        ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
-                if (li > 0) first -= pl.bs_tasks[li - 1].size();
+                if (li == 4)
+                    HIP_TRY(launch_bs_tab(w, (uint32_t)pl.bs_tasks[li].size(), umi_len, s));
+                else
+                    HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
+                                            ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
             }
             PairArgs big = a;
             big.tasks = a.tasks + pl.small_tasks.size();
@@ -922,6 +945,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->bs_unit = (int)value;
     } else if (!strcmp(name, "bs_sorted")) {
         ctx->bs_sorted = value != 0;
+    } else if (!strcmp(name, "bs_tables")) {
+        ctx->bs_tables = value != 0;
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_max")) {

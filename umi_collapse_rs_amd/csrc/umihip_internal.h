@@ -48,6 +48,7 @@ struct BsTask {
     uint32_t pad;
 };
 
+constexpr int BS_TAB_G2 = 2;    // row groups per lane of the table variant with 2 live units
 constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
 // One wave transposes 64 rows of one bucket into bit planes.
@@ -109,6 +110,7 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int prefix_units, hipStream_t s);
+hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s);
 
 // ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
 size_t sort_temp_bytes(bool key32, uint32_t n);

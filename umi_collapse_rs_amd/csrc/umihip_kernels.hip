@@ -16,6 +16,7 @@
 // dense contraction).
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 
 #include "umihip_internal.h"
 
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
             if ((uint32_t)tid < nc) {
                 newrun = (tid & 31) == 0; // the flags are consumed in words of 32 columns
                 if (!newrun) {
-                    constexpr int shift = (sizeof(KeyT) == 4 ? 2 : 3) * GB * LIVE; // bits below the prefix
+                    constexpr int shift = PU > 0 ? (sizeof(KeyT) == 4 ? 2 : 3) * GB * LIVE : 0; // bits below the prefix
                     newrun = ((fkey[c0 + tid] ^ fkey[c0 + tid - 1]) >> shift) != 0;
                 }
             }
@@ -683,6 +684,355 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
         if (tid == 0) hitq_count = 0;
         flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
                              c0 + BS_COL_TILE >= col1);
+    }
+    __syncthreads();
+    if (tid == 0 && stage.candidates)
+        atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
+}
+
+// ---- table variant of the bit-sliced filter (key-sorted buckets, 32-bit keys) -------
+// The mask "rows whose 2-base unit u differs from value v" depends on the rows only, so for
+// the LIVE lowest units a lane keeps all 16 of them in registers (one table of 16 words per
+// unit, built once per row tile: two bitop3 per entry).  A column then selects its LIVE entries
+// with its own unit values as the index -- wave-uniform, read from the sorted key array with a
+// scalar load -- and merges them with the cached state of the PU = U - LIVE high units, which is
+// recomputed from LDS masks only where a column's high bases differ from its predecessor's.
+// The common column costs LIVE register-indexed moves and two or three bitop3 and touches no
+// LDS: the mask formulation above it is bound by the LDS return path (1 KB per 128-bit
+// broadcast read and wave, ~30 cycles per read and SIMD when all four SIMDs pull), not by VALU.
+// One row group per lane (the tables take the registers a second group's planes had).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// rows whose unit (planes q.x .. q.w) differs from the 4-bit value V:
+// (P0 ^ b0) | (P1 ^ b1) | (P2 ^ b2) in one op, then | (P3 ^ b3); b = bits of V
+template <int V> __device__ __forceinline__ uint32_t unit_differs_from(const uint4 &q)
+{
+    constexpr unsigned t3 = ((V & 1) ? (~TT_A & 0xFFu) : TT_A) | ((V & 2) ? (~TT_B & 0xFFu) : TT_B) |
+                            ((V & 4) ? (~TT_C & 0xFFu) : TT_C);
+    constexpr unsigned t2 = TT_A | ((V & 8) ? (~TT_B & 0xFFu) : TT_B);
+    const uint32_t x = BITOP3(q.x, q.y, q.z, t3);
+    return BITOP3(x, q.w, q.w, t2);
+}
+template <int... V>
+__device__ __forceinline__ u32x16 unit_table(const uint4 &q, std::integer_sequence<int, V...>)
+{
+    u32x16 t;
+    ((t[V] = unit_differs_from<V>(q)), ...);
+    return t;
+}
+
+template <int LP, int K, int LIVE, int G>
+__global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
+{
+    constexpr int THREADS = 256;
+    constexpr int NP = 2 * LP;
+    constexpr int U = LP / 2;      // 2-base units per key
+    constexpr int PU = U - LIVE;   // prefix units: masks from LDS, state cached per column run
+    constexpr int PW = 4 * PU;     // prefix mask words per column
+    constexpr int TILE = BS_COL_TILE; // columns staged per barrier pair
+    static_assert(LIVE >= 1 && LIVE <= 4 && PU >= 1, "table variant: 1..4 live units and a prefix");
+    static_assert(LIVE == 2 && G == 2, "only the tuned shape is instantiated (launch_bs_tab)");
+    __shared__ __attribute__((aligned(16))) uint32_t pmask[TILE * PW];
+    __shared__ uint32_t runbits[TILE / 32];
+    __shared__ uint32_t ckey[TILE + 8]; // the tile's column keys (+ the group read ahead past its end)
+    constexpr uint32_t HITQ = 1024;
+    __shared__ uint2 hitq[HITQ];
+    __shared__ unsigned int hitq_count;
+    __shared__ EdgeStage stage;
+    const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x;
+    const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(tp->bucket_start);
+    const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(tp->bucket_end);
+    const uint32_t group0 = __builtin_amdgcn_readfirstlane(tp->group0);
+    const uint32_t ngroups = __builtin_amdgcn_readfirstlane(tp->ngroups);
+    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0);
+    const uint32_t col1 = __builtin_amdgcn_readfirstlane(tp->col1);
+    const bool diag = __builtin_amdgcn_readfirstlane(tp->diag) != 0; // wave-uniform
+    const uint32_t *__restrict__ fkey = (const uint32_t *)a.fkey;
+    const uint32_t *__restrict__ planes = a.planes + tp->plane_off;
+    const int tid = threadIdx.x;
+    const bool with_dist = a.mode == MODE_NEIGHBOURS;
+    const uint32_t n_rows = bucket_end - bucket_start;
+
+    if (tid == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+        hitq_count = 0;
+    }
+
+    uint32_t rbase[G], valid[G]; // bucket-relative index of the group's first row; its rows in range
+    uint32_t pp[G][PW];          // planes of the prefix units (quads: word j = plane 4q + j)
+    // tXY[v] = rows of group X whose live unit Y differs from value v.  Eight named vectors, not
+    // an array: an array of vectors this large stays in scratch memory instead of registers.
+    u32x16 t00 = {}, t01 = {}, t02 = {}, t03 = {}, t10 = {}, t11 = {}, t12 = {}, t13 = {};
+    static_assert(G <= 2, "two table sets");
+    auto set_table = [&](int g, int u, const u32x16 &t) {
+        switch (g * 4 + u) {
+        case 0: t00 = t; break;
+        case 1: t01 = t; break;
+        case 2: t02 = t; break;
+        case 3: t03 = t; break;
+        case 4: t10 = t; break;
+        case 5: t11 = t; break;
+        case 6: t12 = t; break;
+        default: t13 = t; break;
+        }
+    };
+    auto lookup = [&](int g, int u, uint32_t v) -> uint32_t { // g, u: constants once unrolled
+        switch (g * 4 + u) {
+        case 0: return t00[v];
+        case 1: return t01[v];
+        case 2: return t02[v];
+        case 3: return t03[v];
+        case 4: return t10[v];
+        case 5: return t11[v];
+        case 6: return t12[v];
+        default: return t13[v];
+        }
+    };
+    uint32_t pre[G][K + 2];      // counter state after the prefix units ((any, two) for K = 1)
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const uint32_t grp = group0 + g * THREADS + tid;
+        rbase[g] = grp * 32;
+        valid[g] = rbase[g] >= n_rows ? 0u
+                   : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
+        auto load_quad = [&](int q) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (grp < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp * NP + 4 * q);
+            return v;
+        };
+#pragma unroll
+        for (int u = 0; u < LIVE; u++)
+            set_table(g, u, unit_table(load_quad(u), std::make_integer_sequence<int, 16>{}));
+#pragma unroll
+        for (int q = 0; q < PU; q++) {
+            const uint4 v = load_quad(LIVE + q);
+            pp[g][4 * q] = v.x;
+            pp[g][4 * q + 1] = v.y;
+            pp[g][4 * q + 2] = v.z;
+            pp[g][4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int l = 0; l < K + 2; l++) pre[g][l] = 0u;
+    }
+
+    for (uint32_t c0 = col0; c0 < col1; c0 += TILE) {
+        const uint32_t nc = min((uint32_t)TILE, col1 - c0);
+        __syncthreads();
+        { // stage the prefix masks: thread -> (column, quad); word j of a quad = plane 4q + (j ^ 1)
+            constexpr int ITEMS = (TILE * PU + THREADS - 1) / THREADS;
+            uint32_t ck[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const uint32_t c = ((uint32_t)tid + (uint32_t)it * THREADS) / PU;
+                ck[it] = c < nc ? fkey[c0 + c] : 0u;
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const uint32_t w = (uint32_t)tid + (uint32_t)it * THREADS;
+                const uint32_t c = w / PU, q = w % PU;
+                if (c < nc) {
+                    const uint32_t bits = ck[it] >> (4 * (LIVE + q));
+                    uint4 v;
+                    v.x = (bits & 2u) ? 0xFFFFFFFFu : 0u;
+                    v.y = (bits & 1u) ? 0xFFFFFFFFu : 0u;
+                    v.z = (bits & 8u) ? 0xFFFFFFFFu : 0u;
+                    v.w = (bits & 4u) ? 0xFFFFFFFFu : 0u;
+                    *reinterpret_cast<uint4 *>(&pmask[c * PW + 4 * q]) = v;
+                }
+            }
+        }
+        for (uint32_t cc = tid; cc < (uint32_t)TILE + 8; cc += THREADS) ckey[cc] = fkey[c0 + cc]; // (padded array)
+        for (uint32_t cc = tid; cc < (uint32_t)TILE; cc += THREADS) { // does column cc start a run of equal high bases?
+            bool newrun = false;
+            if (cc < nc) // the first column of the task, or high bases unlike the column before
+                newrun = c0 + cc == col0 || ((fkey[c0 + cc] ^ fkey[c0 + cc - 1]) >> (4 * LIVE)) != 0;
+            const unsigned long long bal = __ballot(newrun);
+            if ((tid & 63) == 0) {
+                runbits[2 * (cc >> 6)] = (uint32_t)bal;
+                runbits[2 * (cc >> 6) + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        __syncthreads();
+
+        auto walk_columns = [&](auto diag_tag) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
+            constexpr int NCOL = 4; // columns per "any hit?" test
+            auto update_prefix = [&](uint32_t c) {
+                uint32_t cm[PW];
+#pragma unroll
+                for (int q = 0; q < PU; q++)
+                    *reinterpret_cast<uint4 *>(&cm[4 * q]) = *reinterpret_cast<const uint4 *>(&pmask[c * PW + 4 * q]);
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    auto unit = [&](int u) { // u = 0 .. PU-1 over the prefix units
+                        uint32_t m = BITOP3(pp[g][4 * u], cm[(4 * u) ^ 1], cm[(4 * u) ^ 1], TT_A ^ TT_B);
+#pragma unroll
+                        for (int b = 1; b < 4; b++)
+                            m = BITOP3(m, pp[g][4 * u + b], cm[(4 * u + b) ^ 1], TT_A | (TT_B ^ TT_C));
+                        return m;
+                    };
+                    if (K == 1) {
+                        any_two_of_units<0, PU>(unit, pre[g][0], pre[g][1]);
+                    } else {
+                        uint32_t s[K + 2];
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) s[l] = 0;
+                        count_units<K, 0, PU>(unit, s);
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) pre[g][l] = s[l];
+                    }
+                }
+            };
+            // rows within the filter's reach of column c, whose (sorted) key is `key`
+            auto eval_column = [&](uint32_t c, uint32_t key, uint32_t (&h)[G]) -> uint32_t {
+                uint32_t anyhit = 0;
+                uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u};
+                if (LIVE == 2 && G == 2) {
+                    // The four lookups of a column under one index-mode window: the compiler
+                    // brackets every indexed move with its own s_set_gpr_idx_on/off, and the one
+                    // scalar unit of a CU (one instruction per 4 cycles and SIMD) is what bounds
+                    // this loop.  The tables are pinned to v[64:127] for the statement.
+                    const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
+                    const uint32_t i0 = ukey & 15u, i1 = (ukey >> 4) & 15u;
+                    asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                        "v_mov_b32 %0, v64\n\t"
+                        "v_mov_b32 %1, v96\n\t"
+                        "s_set_gpr_idx_idx %5\n\t"
+                        "v_mov_b32 %2, v80\n\t"
+                        "v_mov_b32 %3, v112\n\t"
+                        "s_set_gpr_idx_off"
+                        : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(f2[0]), "=&v"(f2[1])
+                        : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t10),
+                          "{v[112:127]}"(t11));
+                    // (m0 is rewritten by the window; the compiler never keeps a value in m0
+                    // across statements, and lists it as reserved, so it is not a clobber here)
+                }
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    auto unit = [&](int u) {
+                        if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
+                        return lookup(g, u, (key >> (4 * u)) & 15u);
+                    };
+                    uint32_t hg;
+                    if (K == 1) {
+                        if (LIVE == 1) {
+                            hg = BITOP3(pre[g][1], pre[g][0] & unit(0), valid[g], ~(TT_A | TT_B) & TT_C);
+                        } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
+                            const uint32_t t = BITOP3(pre[g][0], unit(0), unit(1),
+                                                      (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                        } else {
+                            uint32_t any, two;
+                            any_two_of_units<0, LIVE>(unit, any, two);
+                            const uint32_t t = BITOP3(two, pre[g][0], any, TT_A | (TT_B & TT_C));
+                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                        }
+                    } else {
+                        uint32_t s[K + 2];
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) s[l] = pre[g][l];
+                        count_units<K, 0, LIVE>(unit, s);
+                        hg = ~s[K + 1] & valid[g];
+                    }
+                    if (DIAG) { // only rows before the column: keeps the self pair and i > j out
+                        const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
+                        const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
+                        hg &= lt;
+                    }
+                    h[g] = hg;
+                    anyhit |= hg;
+                }
+                return anyhit;
+            };
+            auto queue_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    uint32_t hh = h[g];
+                    while (hh) {
+                        const int j = __builtin_ctz(hh);
+                        hh &= hh - 1;
+                        const uint32_t row = bucket_start + rbase[g] + j;
+                        const unsigned int slot = atomicAdd(&hitq_count, 1u);
+                        if (slot < HITQ)
+                            hitq[slot] = make_uint2(row, c0 + c);
+                        else // queue full (a very dense tile): check it here and now
+                            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
+                                        &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
+                                        row, c0 + c, a.perm);
+                    }
+                }
+            };
+            // run by run: new prefix state where the flag says so, then the run's columns in
+            // groups of NCOL (one hit test per group) and singly at its end.  All of this
+            // bookkeeping is wave-uniform: scalar instructions and scalar branches.
+            uint32_t rb[TILE / 32];
+#pragma unroll
+            for (int w = 0; w < TILE / 32; w++) rb[w] = __builtin_amdgcn_readfirstlane(runbits[w]);
+            auto flag_word = [&](uint32_t w) {
+                uint32_t v = rb[0];
+#pragma unroll
+                for (int i = 1; i < TILE / 32; i++) v = w == (uint32_t)i ? rb[i] : v;
+                return v;
+            };
+            auto next_start = [&](uint32_t c) -> uint32_t { // first flagged column after c, or nc
+                uint32_t q = c + 1;
+                while (q < nc) {
+                    const uint32_t m = flag_word(q >> 5) >> (q & 31);
+                    if (m) return min(nc, q + (uint32_t)__builtin_ctz(m));
+                    q = ((q >> 5) + 1) << 5;
+                }
+                return nc;
+            };
+            // keys of columns c .. c+NCOL-1, read from the LDS copy one group ahead of their use
+            // (wave-wide reads of one address, then v_readfirstlane: LDS returns in order, so the
+            // wait for a group's keys does not drain the reads issued after them; scalar loads
+            // from the key array itself would, and they miss the scalar cache every 16 columns)
+            uint32_t next[NCOL];
+#pragma unroll
+            for (int i = 0; i < NCOL; i++) next[i] = ckey[i];
+            uint32_t c = 0;
+            while (c < nc) {
+                c = __builtin_amdgcn_readfirstlane(c); // (uniform already; keeps it in an SGPR)
+                if ((flag_word(c >> 5) >> (c & 31)) & 1u) update_prefix(c);
+                const uint32_t e = __builtin_amdgcn_readfirstlane(next_start(c));
+                for (; c + NCOL <= e; c += NCOL) {
+                    uint32_t key[NCOL], h[NCOL][G];
+#pragma unroll
+                    for (int i = 0; i < NCOL; i++) key[i] = __builtin_amdgcn_readfirstlane(next[i]);
+#pragma unroll
+                    for (int i = 0; i < NCOL; i++) next[i] = ckey[c + NCOL + i];
+                    uint32_t anyhit = 0;
+#pragma unroll
+                    for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i, key[i], h[i]);
+                    if (__any(anyhit != 0)) {
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
+                    }
+                }
+                for (; c < e; c++) {
+                    uint32_t hh[G];
+                    const uint32_t key = __builtin_amdgcn_readfirstlane(next[0]);
+#pragma unroll
+                    for (int i = 0; i + 1 < NCOL; i++) next[i] = next[i + 1];
+                    next[NCOL - 1] = ckey[c + NCOL];
+                    if (__any(eval_column(c, key, hh) != 0)) queue_hits(c, hh);
+                }
+            }
+        };
+        if (diag) walk_columns(std::true_type{});
+        else walk_columns(std::false_type{});
+
+        __syncthreads();
+        const uint32_t nq = min(hitq_count, HITQ);
+        for (uint32_t i = tid; i < nq; i += THREADS)
+            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x, hitq[i].y,
+                        a.perm);
+        __syncthreads();
+        if (tid == 0) hitq_count = 0;
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
+                             c0 + TILE >= col1);
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
@@ -1302,6 +1652,36 @@ void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int 
     }
 }
 } // namespace
+
+namespace {
+template <int LP, int K>
+void launch_tab_k(const PairArgs &a, uint32_t n_tasks, hipStream_t s)
+{
+    // two live units looked up in the tables, the other LP/2 - 2 cached per column run
+    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_tasks, 256, 0, s>>>(a);
+}
+template <int LP>
+void launch_tab_lp(const PairArgs &a, uint32_t n_tasks, hipStream_t s)
+{
+    switch (a.k) {
+    case 0: launch_tab_k<LP, 0>(a, n_tasks, s); break;
+    case 1: launch_tab_k<LP, 1>(a, n_tasks, s); break;
+    case 2: launch_tab_k<LP, 2>(a, n_tasks, s); break;
+    default: launch_tab_k<LP, 3>(a, n_tasks, s); break;
+    }
+}
+} // namespace
+
+// table variant: 32-bit keys, key-sorted buckets, BS_TAB_G2 row groups per lane, 2 live units
+hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s)
+{
+    if (n_tasks == 0) return hipSuccess;
+    const int lp = bs_padded_len(umi_len);
+    if (lp == 8) launch_tab_lp<8>(a, n_tasks, s);
+    else if (lp == 12) launch_tab_lp<12>(a, n_tasks, s);
+    else launch_tab_lp<16>(a, n_tasks, s);
+    return hipGetLastError();
+}
 
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int pu, hipStream_t s)
