@@ -26,6 +26,8 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_CONFIG2 = (397161.4 + 23819.8) * 1024  # bytes per bs_tab_kernel launch at config 2:
+# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v5_tab.csv
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
 # and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
 # counter over the L'/unit units: 0.5 per unit for K = 0, K+1 per unit for K > 1, and for
@@ -46,6 +48,32 @@ def ops_per_pair(umi_len, k, unit=2):
         counter = (k + 1.0) * units
     return (2.0 * lp + counter) / 32.0
 BYTES_PER_UMI = 16   # 8 B key + 4 B freq in, 4 B label out
+
+
+def table_kernel_shape(n_max, umi_len, opts):
+    """Mirror of choose_live_units (csrc/umihip_api.cpp): does the largest bucket go through the
+    table variant (key-sorted, 32-bit keys, 2 live units)?  Returns (live, prefix_units, run)."""
+    if umi_len > 16 or opts.get("bs_sorted", 1) == 0 or opts.get("bs_tables", 1) == 0 \
+            or opts.get("bs_unit", 2) != 2 or opts.get("prune", 0) or opts.get("bitslice", 1) == 0:
+        return None
+    lp = 8 if umi_len <= 8 else 12 if umi_len <= 12 else 16
+    units, pad = lp // 2, lp - umi_len
+    if units <= 2 or n_max < 32768:
+        return None
+    bases = max(0, 2 * (units - 2) - pad)
+    if (n_max >> (2 * bases)) < 4:
+        return None
+    return 2, units - 2, n_max / 4.0 ** bases
+
+
+def table_ops_per_pair(k, shape):
+    """Algorithmic lane-ops per pair of bs_tab_kernel: per column and 32-row group `live`
+    register-indexed moves and the merge (2 bitop3 for k = 1, (k+1) per live unit otherwise),
+    plus the prefix state (4 mask ops per prefix unit and its counter ops) once per column run."""
+    live, pu, run = shape
+    merge = 2.0 if k == 1 else (0.5 * live if k == 0 else (k + 1.0) * live)
+    tree = {0: 0.5 * pu, 1: 2.0 * (pu // 3) + (pu % 3) + max(0, (pu + 2) // 3 - 1)}.get(k, (k + 1.0) * pu)
+    return (live + merge + (4.0 * pu + tree) / max(run, 1.0)) / 32.0
 
 
 def cpu_baseline(st, n_sample, k, p, umi_len=12, config=2):
@@ -80,7 +108,7 @@ def cpu_baseline(st, n_sample, k, p, umi_len=12, config=2):
     # drops the GIL inside the oracle call).  Reported beside `value`, never instead of it.
     import os
     from concurrent.futures import ThreadPoolExecutor
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # the box's CPU share for one GPU
     if cores > 1:
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
@@ -245,11 +273,15 @@ def main():
         pair_ms = float(np.mean([s["ms_pairs"] for s in stats]))
         coll_ms = float(np.mean([s["ms_collapse"] for s in stats]))
         s0 = stats[-1]
-        unit = 2
-        for o in args.opt:
-            if o.startswith("bs_unit="):
-                unit = int(o.split("=")[1])
-        opp = ops_per_pair(args.umi_len, args.k, unit)
+        opts = {o.split("=")[0]: int(o.split("=")[1]) for o in args.opt}
+        n_max = int(np.diff(st["bucket_off"].astype(np.int64)).max())
+        shape = table_kernel_shape(n_max, args.umi_len, opts) if args.k <= 3 and not split else None
+        if shape:
+            opp = table_ops_per_pair(args.k, shape)
+            kernel_name = "bs_tab_kernel (bit-sliced filter, key-sorted columns, register tables)"
+        else:
+            opp = ops_per_pair(args.umi_len, args.k, opts.get("bs_unit", 2))
+            kernel_name = "bs_pair_kernel (bit-sliced all-pairs filter)"
         # --split: each rank's pair kernels cover 1/world of W
         achieved = opp * (w_local / world if split else w_local) / (max(pair_ms, 1e-6) * 1e-3) / 1e12
         out = {
@@ -273,20 +305,23 @@ def main():
                 "note": "umi_dedup_batch with pageable host arrays: PCIe copies included"},
             "kept_rank0": kept_n,
             "roofline": {
-                "bound": "valu", "kernel": "bs_pair_kernel (bit-sliced all-pairs filter)",
+                "bound": "valu", "kernel": kernel_name,
                 "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
                 "frac": achieved / VALU_PEAK_TLANEOPS,
                 # fabric-side bytes of one pair-kernel launch at config 2 from the PMC passes in
-                # profiles/r01_config2_pmc_fetch_write_summary.csv ((FETCH_SIZE+WRITE_SIZE)*1024,
-                # uncorrected: 4 B/lane accesses, see profiles/README.md); other shapes: null
-                "traffic": 244.0e6 if (args.config == 2 and args.reads == 1_000_000
-                                        and args.umi_len == 12 and args.k == 1) else None,
+                # profiles/ ((FETCH_SIZE+WRITE_SIZE)*1024, uncorrected: 4 B/lane accesses, see
+                # profiles/README.md); other shapes: null
+                "traffic": TRAFFIC_CONFIG2 if (shape and args.config == 2 and args.reads == 1_000_000
+                                               and args.umi_len == 12 and args.k == 1) else None,
                 "ops_per_pair": opp, "pairs_per_launch": w_local,
                 "kernel_ms": pair_ms,
-                "note": "integer VALU-bound (0 algorithmic HBM bytes per pair, LDS-staged "
-                        "column masks); no MFMA.  achieved = ops_per_pair x W / time of the pair "
-                        "kernels of one step (HIP events); peak = 256 CU x 4 SIMD x 32 lanes x "
-                        "2.4 GHz.  HBM view in roofline_hbm."},
+                "note": "integer VALU roofline (0 algorithmic HBM bytes per pair; no MFMA).  "
+                        "achieved = ops_per_pair x W / time of the pair kernels of one step (HIP "
+                        "events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The table kernel "
+                        "needs 5.7x fewer lane-ops per pair than the mask kernel it replaced "
+                        "(0.165 vs 0.94 at L=12, k=1) and is bound by per-wave instruction issue "
+                        "and the scalar unit, not by VALU throughput: frac fell while pairs/s rose "
+                        "(DESIGN.md section 7).  HBM view in roofline_hbm."},
             "roofline_hbm": {
                 "bound": "hbm", "achieved": BYTES_PER_UMI * n / (ms_step * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
