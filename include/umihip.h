@@ -77,6 +77,11 @@ const char *umi_last_error(void);
  * kernel, 0..128, default 128), "fused_sliced" (0/1: that kernel's bit-sliced body, default 1;
  * it is used for k <= 3, the column-walking body otherwise), "bs_unit" (bases per counted unit of the bit-sliced filter:
  * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2),
+ * "bs_sorted" (0/1, default 1: buckets of >= 32768 entries are sorted by filter key on the
+ * device and the tile kernels reuse the evaluation of the high bases along runs of columns
+ * that agree in them -- every pair is still evaluated), "bs_tables" (0/1, default 1: with
+ * bs_sorted and 32-bit keys, the two lowest 2-base units of a column are looked up in
+ * per-lane register tables instead of being compared plane by plane),
  * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
  * cannot hold a pair within k -- same result, fewer comparisons executed).
  * Unknown name -> UMI_ERR_ARG. */
