@@ -82,6 +82,9 @@ const char *umi_last_error(void);
  * that agree in them -- every pair is still evaluated), "bs_tables" (0/1, default 1: with
  * bs_sorted and 32-bit keys, the two lowest 2-base units of a column are looked up in
  * per-lane register tables instead of being compared plane by plane),
+ * "two_phase" (0/1, default 1: directional collapse as connected components of the symmetric
+ * pairs followed by propagation along the one-way pairs; 0 = plain label propagation over all
+ * pairs, one hop per round),
  * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
  * cannot hold a pair within k -- same result, fewer comparisons executed).
  * Unknown name -> UMI_ERR_ARG. */

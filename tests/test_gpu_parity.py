@@ -8,16 +8,20 @@ from helpers import canonical, random_bucket
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["default", "nofuse", "prune", "fused_walk"])
+@pytest.fixture(scope="module", params=["default", "nofuse", "prune", "fused_walk", "label_prop"])
 def ctx(request):
     """default: fused one-wave kernel for buckets <= 128, popcount chunks to 1024, bit-sliced
     tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list.
     prune: every bucket > 128 through key-sorted bit-sliced tiles with range pruning.
-    fused_walk: the fused kernel's column-walking body instead of its bit-sliced one."""
+    fused_walk: the fused kernel's column-walking body instead of its bit-sliced one.
+    label_prop: no fused kernel, and plain label propagation instead of the two-phase collapse."""
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
     if request.param == "nofuse":
         c.set_option("fused_max", 0)
+    if request.param == "label_prop":
+        c.set_option("fused_max", 0)
+        c.set_option("two_phase", 0)
     if request.param == "fused_walk":
         c.set_option("fused_sliced", 0)
     if request.param == "prune":

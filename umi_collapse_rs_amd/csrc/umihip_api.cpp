@@ -122,8 +122,9 @@ struct umi_ctx {
     int bs_unit = 2;
     bool bs_sorted = true; // sort large buckets by key and reuse prefix state along column runs
     bool bs_tables = true; // ... and look the low units up in per-lane register tables (32-bit keys)
+    bool two_phase = true; // directional collapse: components of the symmetric pairs, then the DAG
     // workspace
-    DevBuf fkey, thr, label, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
+    DevBuf fkey, thr, label, lab, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
@@ -299,6 +300,56 @@ int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, i
         return fail(UMI_ERR_ARG, "%llu entries exceed the 31-bit index space of one call",
                     (unsigned long long)n);
     *n_out = n;
+    return UMI_OK;
+}
+
+// rounds of one propagation phase until a whole round changes nothing; the per-round flags
+// are checked on the device (a round after a quiet one returns at once), the host looks
+// every `batch` rounds
+template <class LaunchRound>
+int run_rounds(umi_ctx *ctx, hipStream_t s, LaunchRound launch_round, int &rounds, int batch = 4)
+{
+    uint32_t *d_changed = ctx->changed.as<uint32_t>();
+    for (;;) {
+        HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
+        for (int r = 0; r < batch; r++) HIP_TRY(launch_round(d_changed, r));
+        HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        bool done = false;
+        for (int r = 0; r < batch && !done; r++) {
+            rounds++;
+            done = ctx->h_changed[r] == 0;
+        }
+        if (done) return UMI_OK;
+        if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
+        batch = std::min(2 * batch, MAX_ROUNDS_PER_SYNC);
+    }
+}
+
+// label[v] = smallest rank that reaches v over the permitted-edge list (directional.rs:30-54,
+// 78-88); ctx->label holds the start labels (v itself, or what the fused kernel left)
+int directional_labels(umi_ctx *ctx, const uint2 *d_edges, unsigned long long *d_cnt, uint32_t edge_cap,
+                       uint64_t n_edges, uint32_t n, hipStream_t s, int &rounds)
+{
+    int rc;
+    uint32_t *d_label = ctx->label.as<uint32_t>();
+    if (!ctx->two_phase)
+        return run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
+            return launch_prop_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
+        }, rounds);
+    if ((rc = ctx->lab.reserve((size_t)n * 4))) return rc;
+    uint32_t *d_lab = ctx->lab.as<uint32_t>();
+    HIP_TRY(launch_iota(d_lab, n, s));
+    if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
+             return launch_cc_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
+         }, rounds, 6))) // a giant component of 10^6 entries settles in 5
+        return rc;
+    if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
+             return launch_dag_round(d_edges, d_cnt, edge_cap, d_label, d_lab, n, d_changed, r,
+                                     (uint32_t)n_edges, s);
+         }, rounds, 3))) // freq at least halves along a one-way pair at p <= 0.5
+        return rc;
+    HIP_TRY(launch_map_labels(d_label, d_lab, n, s));
     return UMI_OK;
 }
 
@@ -689,26 +740,9 @@ class Pipeline {
     int collapse_directional()
     {
         if (n_edges) {
-            uint32_t *d_changed = ctx->changed.as<uint32_t>();
-            int rounds = 0, batch = 4;
-            for (;;) {
-                HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
-                for (int r = 0; r < batch; r++)
-                    HIP_TRY(launch_prop_round(ctx->edges.as<uint2>(), d_cnt, cap_used,
-                                              ctx->label.as<uint32_t>(), n, d_changed, r,
-                                              (uint32_t)n_edges, s));
-                HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch,
-                                       hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                bool done = false;
-                for (int r = 0; r < batch && !done; r++) {
-                    rounds++;
-                    done = ctx->h_changed[r] == 0;
-                }
-                if (done) break;
-                if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
-                batch = std::min(2 * batch, MAX_ROUNDS_PER_SYNC);
-            }
+            int rounds = 0;
+            const int rc = directional_labels(ctx, ctx->edges.as<uint2>(), d_cnt, cap_used, n_edges, n, s, rounds);
+            if (rc) return rc;
             st.n_rounds = (uint32_t)rounds;
         }
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
@@ -808,25 +842,8 @@ class EdgeCollapse {
         st.n_edges = n_edges;
         if (mode == MODE_DIRECTIONAL) {
             if (n_edges) {
-                uint32_t *d_changed = ctx->changed.as<uint32_t>();
-                int rounds = 0, batch = 4;
-                for (;;) {
-                    HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
-                    for (int r = 0; r < batch; r++)
-                        HIP_TRY(launch_prop_round(d_edges, d_cnt, n_edges, ctx->label.as<uint32_t>(), n,
-                                                  d_changed, r, n_edges, s));
-                    HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch,
-                                           hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    bool done = false;
-                    for (int r = 0; r < batch && !done; r++) {
-                        rounds++;
-                        done = ctx->h_changed[r] == 0;
-                    }
-                    if (done) break;
-                    if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
-                    batch = std::min(2 * batch, MAX_ROUNDS_PER_SYNC);
-                }
+                int rounds = 0;
+                if ((rc = directional_labels(ctx, d_edges, d_cnt, n_edges, n_edges, n, s, rounds))) return rc;
                 st.n_rounds = (uint32_t)rounds;
             }
             HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
@@ -916,7 +933,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->fkey_sorted, &ctx->perm,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
-                      &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->edges,
+                      &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
@@ -947,6 +964,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->bs_sorted = value != 0;
     } else if (!strcmp(name, "bs_tables")) {
         ctx->bs_tables = value != 0;
+    } else if (!strcmp(name, "two_phase")) {
+        ctx->two_phase = value != 0;
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_max")) {

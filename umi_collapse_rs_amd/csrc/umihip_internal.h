@@ -139,6 +139,14 @@ hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *count
 
 // label[i] = i (collapse of an external edge list)
 hipError_t launch_iota(uint32_t *label, uint32_t n, hipStream_t s);
+// two-phase directional collapse: components over the symmetric pairs, then the DAG of one-way pairs
+hipError_t launch_cc_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                           uint32_t *comp, uint32_t n, uint32_t *changed, int round,
+                           uint32_t n_edges_hint, hipStream_t s);
+hipError_t launch_dag_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                            const uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t *changed,
+                            int round, uint32_t n_edges_hint, hipStream_t s);
+hipError_t launch_map_labels(uint32_t *comp, const uint32_t *lab, uint32_t n, hipStream_t s);
 
 hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
                            unsigned long long *counters, hipStream_t s);

@@ -1497,6 +1497,90 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
     if (any) changed[round] = 1;
 }
 
+// ---- directional collapse in two phases ------------------------------------------
+// Reachability inside a set of entries joined by symmetric pairs (both directions permitted)
+// is symmetric, and a one-way pair always leads to a strictly lower freq (thr is monotone in
+// freq), so the one-way pairs form a DAG over those sets.  Phase 1: connected components over
+// the symmetric pairs, comp[v] = smallest index of v's set, by hooking parents and
+// grandparents and pointer jumping (a handful of rounds where plain label propagation needs as
+// many as the longest chain is long).  Phase 2: lab[c] = smallest set index that reaches set c,
+// propagated along the one-way pairs (rounds <= depth of the DAG).  Then label[v] = lab[comp[v]],
+// the smallest rank that reaches v: what directional.rs:30-54,78-88 removes v under.
+__global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ edges,
+                                                      const unsigned long long *counters,
+                                                      uint32_t edge_cap, uint32_t *comp,
+                                                      uint32_t *changed, int round)
+{
+    if (round > 0 && changed[round - 1] == 0) return;
+    unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    bool any = false;
+    constexpr int ILP = 4;
+    const uint32_t nth = gridDim.x * blockDim.x;
+    for (uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < E; e0 += ILP * nth) {
+        uint2 uv[ILP];
+        uint32_t fu[ILP], fv[ILP], gu[ILP], gv[ILP];
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            const uint32_t e = e0 + i * nth;
+            uv[i] = e < E ? edges[e] : make_uint2(0u, 0u); // (0, 0) is not a symmetric pair
+        }
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            const bool sym = (uv[i].x & SYM_FLAG) != 0;
+            fu[i] = sym ? comp[uv[i].x & ~SYM_FLAG] : 0u;
+            fv[i] = sym ? comp[uv[i].y] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            const bool live = fu[i] != fv[i]; // same parent: nothing to learn from this pair
+            gu[i] = live ? comp[fu[i]] : 0u;
+            gv[i] = live ? comp[fv[i]] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            if (fu[i] == fv[i]) continue;
+            const uint32_t lo = min(gu[i], gv[i]); // a member of the set, <= everything below
+            if (lo < gu[i]) atomicMin(&comp[fu[i]], lo); // the parent with the larger grandparent
+            if (lo < gv[i]) atomicMin(&comp[fv[i]], lo);
+            if (lo < fu[i]) atomicMin(&comp[uv[i].x & ~SYM_FLAG], lo);
+            if (lo < fv[i]) atomicMin(&comp[uv[i].y], lo);
+            any = true; // parents differ: one of the four moved, or will once the jump has run
+        }
+    }
+    if (any) changed[round] = 1;
+}
+
+__global__ __launch_bounds__(256) void dag_hook_kernel(const uint2 *__restrict__ edges,
+                                                       const unsigned long long *counters,
+                                                       uint32_t edge_cap,
+                                                       const uint32_t *__restrict__ comp,
+                                                       uint32_t *lab, uint32_t *changed, int round)
+{
+    if (round > 0 && changed[round - 1] == 0) return;
+    unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    bool any = false;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const uint2 uv = edges[e];
+        if (uv.x & SYM_FLAG) continue;
+        const uint32_t cu = comp[uv.x], cv = comp[uv.y];
+        const uint32_t lu = lab[cu], lv = lab[cv];
+        if (lu < lv) {
+            atomicMin(&lab[cv], lu);
+            any = true;
+        }
+    }
+    if (any) changed[round] = 1;
+}
+
+__global__ __launch_bounds__(256) void map_label_kernel(uint32_t *comp, const uint32_t *__restrict__ lab,
+                                                        uint32_t n)
+{
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+        comp[v] = lab[comp[v]];
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ label,
                                                        uint32_t n, uint8_t *__restrict__ kept,
                                                        uint32_t *__restrict__ root,
@@ -1760,6 +1844,33 @@ hipError_t launch_prop_round(const uint2 *edges, const unsigned long long *count
     hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, label,
                                                             changed, round);
     jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(label, n, changed, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_cc_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                           uint32_t *comp, uint32_t n, uint32_t *changed, int round,
+                           uint32_t n_edges_hint, hipStream_t s)
+{
+    cc_hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, comp, changed,
+                                                               round);
+    jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(comp, n, changed, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_dag_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                            const uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t *changed,
+                            int round, uint32_t n_edges_hint, hipStream_t s)
+{
+    dag_hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, comp, lab,
+                                                                changed, round);
+    jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(lab, n, changed, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_labels(uint32_t *comp, const uint32_t *lab, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    map_label_kernel<<<grid_for(n, 256), 256, 0, s>>>(comp, lab, n);
     return hipGetLastError();
 }
 
