@@ -21,12 +21,14 @@ __global__ __launch_bounds__(256) void k(const uint32_t *in, uint32_t *out, unsi
     __shared__ uint32_t pad[8192]; // 32 KB: with waves_pad the block count per CU is set from the host
     if (waves_pad == 12345) pad[threadIdx.x] = 1;
     const int tid = threadIdx.x;
-    u32x16 t00, t01, t10, t11;
+    u32x16 t00, t01, t10, t11, t02, t12;
     for (int i = 0; i < 16; i++) {
         t00[i] = in[(tid + i * 3) & 8191];
         t01[i] = in[(tid + i * 5 + 1) & 8191];
         t10[i] = in[(tid + i * 7 + 2) & 8191];
         t11[i] = in[(tid + i * 11 + 3) & 8191];
+        t02[i] = in[(tid + i * 13 + 4) & 8191];
+        t12[i] = in[(tid + i * 17 + 5) & 8191];
     }
     uint32_t anyP0 = in[tid & 8191], twoP0 = in[(tid + 9) & 8191], anyP1 = in[(tid + 17) & 8191], twoP1 = in[(tid + 31) & 8191];
     const uint32_t valid = 0xFFFFFFFFu;
@@ -49,6 +51,31 @@ __global__ __launch_bounds__(256) void k(const uint32_t *in, uint32_t *out, unsi
             for (int i = 0; i < 4; i++) {
                 uint32_t e0, e1, f0, f1;
                 const uint32_t i0 = key[i] & 15u, i1 = (key[i] >> 4) & 15u;
+                if (MODE == 6) {
+                    uint32_t g0, g1;
+                    const uint32_t i2 = (key[i] >> 8) & 15u;
+                    asm volatile("s_set_gpr_idx_on %6, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "v_mov_b32 %1, v112\n\t"
+                                 "s_set_gpr_idx_idx %7\n\t"
+                                 "v_mov_b32 %2, v80\n\t"
+                                 "v_mov_b32 %3, v128\n\t"
+                                 "s_set_gpr_idx_idx %8\n\t"
+                                 "v_mov_b32 %4, v96\n\t"
+                                 "v_mov_b32 %5, v144\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e0), "=&v"(e1), "=&v"(f0), "=&v"(f1), "=&v"(g0), "=&v"(g1)
+                                 : "s"(i0), "s"(i1), "s"(i2), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t02),
+                                   "{v[112:127]}"(t10), "{v[128:143]}"(t11), "{v[144:159]}"(t12));
+                    const uint32_t anyA = BITOP3(e0, f0, g0, 0xfe), twoA = BITOP3(e0, f0, g0, 0xe8);
+                    const uint32_t ta = BITOP3(twoA, anyP0, anyA, 0xf8);
+                    h[i][0] = BITOP3(twoP0, ta, valid, 0x02);
+                    const uint32_t anyB = BITOP3(e1, f1, g1, 0xfe), twoB = BITOP3(e1, f1, g1, 0xe8);
+                    const uint32_t tb = BITOP3(twoB, anyP1, anyB, 0xf8);
+                    h[i][1] = BITOP3(twoP1, tb, valid, 0x02);
+                    anyhit |= h[i][0] | h[i][1];
+                    continue;
+                }
                 if (MODE == 3) {
                     e0 = t00[3] ^ i0; e1 = t10[5]; f0 = t01[7]; f1 = t11[9] ^ i1;
                 } else {
@@ -112,6 +139,7 @@ int main()
         run<2>("indices from the loop counter", in, out, clk, w);
         run<3>("no index window", in, out, clk, w);
         run<4>("window only", in, out, clk, w);
+        run<6>("three live units (6 tables), tree + merge", in, out, clk, w);
     }
     return 0;
 }

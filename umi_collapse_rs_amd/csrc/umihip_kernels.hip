@@ -674,16 +674,21 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
         else walk_columns(std::false_type{});
 
         // exact check of the tile's filter hits, one per thread
+        // The queued hits are checked when the queue is half full or the task ends, not after
+        // every tile: the check is a chain of dependent global gathers (permutation, keys, freq,
+        // thresholds) that all four waves of the block would sit out 16 times per task.
         __syncthreads();
-        const uint32_t nq = min(hitq_count, HITQ);
-        for (uint32_t i = tid; i < nq; i += THREADS)
-            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x, hitq[i].y,
-                        a.perm);
-        __syncthreads();
-        if (tid == 0) hitq_count = 0;
-        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
-                             c0 + BS_COL_TILE >= col1);
+        const uint32_t queued = hitq_count; // the same for every thread: stable between the barriers
+        if (queued >= HITQ / 2 || c0 + BS_COL_TILE >= col1) {
+            const uint32_t nq = min(queued, HITQ);
+            for (uint32_t i = tid; i < nq; i += THREADS)
+                verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x,
+                            hitq[i].y, a.perm);
+            __syncthreads();
+            if (tid == 0) hitq_count = 0;
+            flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, true);
+        }
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
@@ -1023,16 +1028,21 @@ __global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
         if (diag) walk_columns(std::true_type{});
         else walk_columns(std::false_type{});
 
+        // The queued hits are checked when the queue is half full or the task ends, not after
+        // every tile: the check is a chain of dependent global gathers (permutation, keys, freq,
+        // thresholds) that all four waves of the block would sit out 16 times per task.
         __syncthreads();
-        const uint32_t nq = min(hitq_count, HITQ);
-        for (uint32_t i = tid; i < nq; i += THREADS)
-            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x, hitq[i].y,
-                        a.perm);
-        __syncthreads();
-        if (tid == 0) hitq_count = 0;
-        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist,
-                             c0 + TILE >= col1);
+        const uint32_t queued = hitq_count; // the same for every thread: stable between the barriers
+        if (queued >= HITQ / 2 || c0 + TILE >= col1) {
+            const uint32_t nq = min(queued, HITQ);
+            for (uint32_t i = tid; i < nq; i += THREADS)
+                verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x,
+                            hitq[i].y, a.perm);
+            __syncthreads();
+            if (tid == 0) hitq_count = 0;
+            flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, true);
+        }
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
