@@ -727,7 +727,7 @@ __device__ __forceinline__ u32x16 unit_table(const uint4 &q, std::integer_sequen
 }
 
 template <int LP, int K, int LIVE, int G>
-__global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
+__global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
 {
     constexpr int THREADS = 256;
     constexpr int NP = 2 * LP;
@@ -740,6 +740,7 @@ __global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
     __shared__ __attribute__((aligned(16))) uint32_t pmask[TILE * PW];
     __shared__ uint32_t runbits[TILE / 32];
     __shared__ uint32_t ckey[TILE + 8]; // the tile's column keys (+ the group read ahead past its end)
+    __shared__ uint32_t nxt[TILE];      // first column after c that starts a run (or the tile's end)
     constexpr uint32_t HITQ = 1024;
     __shared__ uint2 hitq[HITQ];
     __shared__ unsigned int hitq_count;
@@ -859,6 +860,18 @@ __global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
             }
         }
         __syncthreads();
+        for (uint32_t cc = tid; cc < nc; cc += THREADS) { // where does the run after column cc begin?
+            uint32_t q = cc + 1, res = nc;
+            for (uint32_t w = q >> 5; w < (uint32_t)TILE / 32; w++) {
+                const uint32_t m = runbits[w] & (w == (q >> 5) ? 0xFFFFFFFFu << (q & 31) : 0xFFFFFFFFu);
+                if (m) {
+                    res = min(nc, w * 32 + (uint32_t)__builtin_ctz(m));
+                    break;
+                }
+            }
+            nxt[cc] = res;
+        }
+        __syncthreads();
 
         auto walk_columns = [&](auto diag_tag) {
             constexpr bool DIAG = decltype(diag_tag)::value;
@@ -968,60 +981,49 @@ __global__ __launch_bounds__(256) void bs_tab_kernel(PairArgs a)
                     }
                 }
             };
-            // run by run: new prefix state where the flag says so, then the run's columns in
-            // groups of NCOL (one hit test per group) and singly at its end.  All of this
-            // bookkeeping is wave-uniform: scalar instructions and scalar branches.
-            uint32_t rb[TILE / 32];
-#pragma unroll
-            for (int w = 0; w < TILE / 32; w++) rb[w] = __builtin_amdgcn_readfirstlane(runbits[w]);
-            auto flag_word = [&](uint32_t w) {
-                uint32_t v = rb[0];
-#pragma unroll
-                for (int i = 1; i < TILE / 32; i++) v = w == (uint32_t)i ? rb[i] : v;
-                return v;
-            };
-            auto next_start = [&](uint32_t c) -> uint32_t { // first flagged column after c, or nc
-                uint32_t q = c + 1;
-                while (q < nc) {
-                    const uint32_t m = flag_word(q >> 5) >> (q & 31);
-                    if (m) return min(nc, q + (uint32_t)__builtin_ctz(m));
-                    q = ((q >> 5) + 1) << 5;
-                }
-                return nc;
-            };
-            // keys of columns c .. c+NCOL-1, read from the LDS copy one group ahead of their use
-            // (wave-wide reads of one address, then v_readfirstlane: LDS returns in order, so the
-            // wait for a group's keys does not drain the reads issued after them; scalar loads
-            // from the key array itself would, and they miss the scalar cache every 16 columns)
+            // run by run: new prefix state at the run's first column, then its columns in groups
+            // of NCOL (one hit test per group); the last group of a run is evaluated whole and
+            // the hit words of the columns past the run's end are dropped (their prefix state is
+            // not theirs).  The bookkeeping is wave-uniform: scalar instructions and branches.
+            // Column keys come from the LDS copy one group ahead of their use (wave-wide reads of
+            // one address, then v_readfirstlane: LDS returns in order, so the wait for a group's
+            // keys does not drain the reads issued after them; scalar loads from the key array
+            // itself would, and they miss the scalar cache every 16 columns).
             uint32_t next[NCOL];
-#pragma unroll
-            for (int i = 0; i < NCOL; i++) next[i] = ckey[i];
+            bool starts = (__builtin_amdgcn_readfirstlane(runbits[0]) & 1u) != 0; // is column 0 a run start?
             uint32_t c = 0;
             while (c < nc) {
                 c = __builtin_amdgcn_readfirstlane(c); // (uniform already; keeps it in an SGPR)
-                if ((flag_word(c >> 5) >> (c & 31)) & 1u) update_prefix(c);
-                const uint32_t e = __builtin_amdgcn_readfirstlane(next_start(c));
-                for (; c + NCOL <= e; c += NCOL) {
+                if (starts) update_prefix(c);
+                starts = true; // every later run of the tile begins at a flagged column
+                const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
+#pragma unroll
+                for (int i = 0; i < NCOL; i++) next[i] = ckey[c + i];
+                while (c < e) {
                     uint32_t key[NCOL], h[NCOL][G];
 #pragma unroll
                     for (int i = 0; i < NCOL; i++) key[i] = __builtin_amdgcn_readfirstlane(next[i]);
 #pragma unroll
                     for (int i = 0; i < NCOL; i++) next[i] = ckey[c + NCOL + i];
+                    const uint32_t cnt = e - c; // columns of this group that belong to the run
                     uint32_t anyhit = 0;
 #pragma unroll
-                    for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i, key[i], h[i]);
+                    for (int i = 0; i < NCOL; i++) {
+                        const uint32_t hit = eval_column(c + i, key[i], h[i]);
+                        if (i == 0) {
+                            anyhit |= hit;
+                        } else if ((uint32_t)i < cnt) { // (wave-uniform)
+                            anyhit |= hit;
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < G; g++) h[i][g] = 0u;
+                        }
+                    }
                     if (__any(anyhit != 0)) {
 #pragma unroll
                         for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
                     }
-                }
-                for (; c < e; c++) {
-                    uint32_t hh[G];
-                    const uint32_t key = __builtin_amdgcn_readfirstlane(next[0]);
-#pragma unroll
-                    for (int i = 0; i + 1 < NCOL; i++) next[i] = next[i + 1];
-                    next[NCOL - 1] = ckey[c + NCOL];
-                    if (__any(eval_column(c, key, hh) != 0)) queue_hits(c, hh);
+                    c += min(cnt, (uint32_t)NCOL);
                 }
             }
         };
