@@ -1573,15 +1573,33 @@ __global__ __launch_bounds__(256) void dag_hook_kernel(const uint2 *__restrict__
     unsigned long long ne = counters[CNT_EDGES];
     const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
     bool any = false;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        const uint2 uv = edges[e];
-        if (uv.x & SYM_FLAG) continue;
-        const uint32_t cu = comp[uv.x], cv = comp[uv.y];
-        const uint32_t lu = lab[cu], lv = lab[cv];
-        if (lu < lv) {
-            atomicMin(&lab[cv], lu);
-            any = true;
+    // (every lane of a wave makes the same number of trips: the shuffles below need them all)
+    for (uint32_t e0 = blockIdx.x * blockDim.x; e0 < E; e0 += gridDim.x * blockDim.x) {
+        const uint32_t e = e0 + threadIdx.x;
+        const uint2 uv = e < E ? edges[e] : make_uint2(SYM_FLAG, 0u);
+        bool todo = false;
+        uint32_t cv = 0, lu = 0;
+        if (!(uv.x & SYM_FLAG)) {
+            const uint32_t cu = comp[uv.x];
+            cv = comp[uv.y];
+            lu = lab[cu];
+            todo = lu < lab[cv];
         }
+        any |= todo;
+        // Many one-way pairs point into the same few sets (the giant component above all), and a
+        // single word takes ~90 atomics per microsecond: the lanes that share the first pending
+        // lane's target send one atomic for their minimum, twice; what is left goes one by one.
+        for (int pass = 0; pass < 2 && __any(todo); pass++) {
+            const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
+            const uint32_t tgt = (uint32_t)__shfl((int)cv, leader);
+            const bool mine = todo && cv == tgt;
+            uint32_t val = mine ? lu : 0xFFFFFFFFu;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) val = min(val, (uint32_t)__shfl_xor((int)val, off));
+            if ((int)(threadIdx.x & 63) == leader) atomicMin(&lab[tgt], val);
+            todo = todo && !mine;
+        }
+        if (todo) atomicMin(&lab[cv], lu);
     }
     if (any) changed[round] = 1;
 }
