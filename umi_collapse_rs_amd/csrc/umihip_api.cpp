@@ -442,6 +442,9 @@ class Pipeline {
         return finish();
     }
 
+    // significant bits of a filter key: 2 per base in 32-bit keys, 3 in 64-bit ones
+    int key_bits() const { return key32 ? 2 * umi_len : std::min(64, 3 * umi_len); }
+
     // keep this rank's share of a task list (round-robin over one running index: the tasks
     // of a list are similar in size and adjacent ones touch the same tiles)
     template <class T> void keep_my_share(std::vector<T> &v)
@@ -550,7 +553,7 @@ class Pipeline {
         const size_t ksz = key32 ? 4 : 8;
         size_t tmp_bytes = 0, n_pos = 0;
         for (auto &bb : pl.bs_buckets) {
-            tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
+            tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s), key_bits()));
             n_pos += (bb.e - bb.s + BS_COL_TILE - 1) / BS_COL_TILE + 1;
         }
         int rc;
@@ -561,7 +564,7 @@ class Pipeline {
         std::vector<uint32_t> pos;
         pos.reserve(n_pos);
         for (auto &bb : pl.bs_buckets) {
-            HIP_TRY(sort_bucket(ctx->fkey.p, key32, (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+            HIP_TRY(sort_bucket(ctx->fkey.p, key32, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                 ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                 ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
             for (uint64_t q = bb.s; q < bb.e; q += BS_COL_TILE) pos.push_back((uint32_t)q);
@@ -597,7 +600,7 @@ class Pipeline {
         size_t tmp_bytes = 0;
         bool all = true;
         for (auto &bb : pl.bs_buckets) {
-            if (bb.pu || bb.live) tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s)));
+            if (bb.pu || bb.live) tmp_bytes = std::max(tmp_bytes, sort_temp_bytes(key32, (uint32_t)(bb.e - bb.s), key_bits()));
             else all = false;
         }
         int rc;
@@ -611,7 +614,7 @@ class Pipeline {
         }
         for (auto &bb : pl.bs_buckets)
             if (bb.pu || bb.live)
-                HIP_TRY(sort_bucket(ctx->fkey.p, key32, (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+                HIP_TRY(sort_bucket(ctx->fkey.p, key32, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                     ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                     ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
         bs_fkey = ctx->fkey_sorted.p;

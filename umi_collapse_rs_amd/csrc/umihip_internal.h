@@ -113,10 +113,10 @@ hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool 
 hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s);
 
 // ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
-size_t sort_temp_bytes(bool key32, uint32_t n);
+size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits);
 // fkey_sorted[start..start+n) = sorted keys, perm[start + i] = original global index of the
 // i-th smallest; iota_tmp is scratch of the same extent
-hipError_t sort_bucket(const void *fkey, bool key32, uint32_t start, uint32_t n, void *fkey_sorted,
+hipError_t sort_bucket(const void *fkey, bool key32, int key_bits, uint32_t start, uint32_t n, void *fkey_sorted,
                        uint32_t *perm, uint32_t *iota_tmp, void *tmp, size_t tmp_bytes,
                        hipStream_t s);
 // out[i] = keys[pos[i]] widened to 64 bits
