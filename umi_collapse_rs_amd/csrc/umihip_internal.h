@@ -98,7 +98,7 @@ hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key3
 // bit-sliced path (buckets larger than small_max, k <= BS_MAX_K)
 constexpr int BS_MAX_K = 3;
 constexpr int BS_COL_TILE = 128;   // columns whose masks are staged in LDS per step
-constexpr int BS_COL_CHUNK = 2048; // default columns per task (ctx option bs_col_chunk)
+constexpr int BS_COL_CHUNK = 1024; // default columns per task (ctx option bs_col_chunk)
 constexpr int BS_WIDE_MIN = 32768; // buckets at least this large use 256-thread blocks
 // planes per key for a umi length: 2 bits per base, base count rounded up to 8/12/16/22
 inline int bs_padded_len(int umi_len) { return umi_len <= 8 ? 8 : umi_len <= 12 ? 12 : umi_len <= 16 ? 16 : 22; }
