@@ -133,6 +133,8 @@ struct umi_ctx {
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
     uint64_t *h_boff = nullptr;               // pinned staging of the bucket table
     size_t h_boff_cap = 0;
+    void *h_tasks = nullptr;                  // pinned staging of the tile-task lists
+    size_t h_tasks_cap = 0;
     unsigned long long *h_counters = nullptr; // pinned
     uint32_t *h_changed = nullptr;            // pinned
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -434,8 +436,15 @@ class Pipeline {
         if ((rc = reserve_core())) return rc;
         if ((rc = upload_and_prep())) return rc;
         if ((rc = plan_and_upload_tasks())) return rc;
-        if (prune && (rc = prune_stage())) return rc;
-        if (!prune && need_pairs && pl.any_sorted() && (rc = sort_stage())) return rc;
+        if (prune) {
+            if ((rc = prune_stage())) return rc;
+        } else {
+            // the sorts are enqueued first: the host cuts the tile tasks (tens of thousands for a
+            // deep position) while they run
+            if (need_pairs && pl.any_sorted() && (rc = sort_stage())) return rc;
+            gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
+            for (auto &v : pl.bs_tasks) keep_my_share(v);
+        }
         if ((rc = upload_bitsliced())) return rc;
         if ((rc = pair_stage())) return rc;
         if (mode == MODE_NEIGHBOURS || n_parts > 1) return finish_neighbours();
@@ -500,11 +509,8 @@ class Pipeline {
                    umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
                    ctx->bs_tables && key32, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
-        if (!prune) gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
         keep_my_share(pl.small_tasks);
         keep_my_share(pl.big_tasks);
-        if (!prune)
-            for (auto &v : pl.bs_tasks) keep_my_share(v);
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
         int rc;
@@ -635,16 +641,27 @@ class Pipeline {
         if (need_pairs && pl.n_bs()) {
             int rc;
             if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask)))) return rc;
-            BsTask *d_bs = ctx->bs_tasks.as<BsTask>();
+            // through a pinned buffer (a megabyte of tasks at config 2: the runtime's staged copy
+            // of pageable memory runs at a fifth of the DMA rate and holds the stream meanwhile)
+            const size_t bs_bytes = pl.n_bs() * sizeof(BsTask);
+            const size_t plane_bytes = pl.plane_tasks.size() * sizeof(PlaneTask);
+            if (ctx->h_tasks_cap < bs_bytes + plane_bytes) {
+                if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
+                ctx->h_tasks = nullptr;
+                ctx->h_tasks_cap = 0;
+                const size_t want = (bs_bytes + plane_bytes) * 5 / 4 + 4096;
+                HIP_TRY(hipHostMalloc(&ctx->h_tasks, want));
+                ctx->h_tasks_cap = want;
+            }
+            char *h = (char *)ctx->h_tasks;
             size_t off = 0;
             for (auto &v : pl.bs_tasks) {
-                if (!v.empty())
-                    HIP_TRY(hipMemcpyAsync(d_bs + off, v.data(), v.size() * sizeof(BsTask),
-                                           hipMemcpyHostToDevice, s));
-                off += v.size();
+                memcpy(h + off, v.data(), v.size() * sizeof(BsTask));
+                off += v.size() * sizeof(BsTask);
             }
-            HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, pl.plane_tasks.data(),
-                                   pl.plane_tasks.size() * sizeof(PlaneTask), hipMemcpyHostToDevice, s));
+            memcpy(h + bs_bytes, pl.plane_tasks.data(), plane_bytes);
+            HIP_TRY(hipMemcpyAsync(ctx->bs_tasks.p, h, bs_bytes, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, h + bs_bytes, plane_bytes, hipMemcpyHostToDevice, s));
             HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
                                         (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
                                         umi_len, s));
@@ -947,6 +964,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
+    if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
     for (int i = 0; i < 6; i++)
