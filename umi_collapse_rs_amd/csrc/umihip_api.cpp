@@ -177,37 +177,39 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
         const uint64_t s = bb.s, e = bb.e;
         const uint32_t tile_groups = bb.live ? 256u * (uint32_t)BS_TAB_G2 : (bb.wide ? 256u : 64u) * gpl;
         const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
+        std::vector<BsTask> &list = pl.bs_tasks[bb.live ? 4 : (!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1)))];
         auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
         auto key_hi = [&](uint64_t end) { // an upper bound of the last key of [.., end)
             if (end >= e) return smp->back();
             const uint64_t idx = (end - s + BS_COL_TILE - 1) / BS_COL_TILE;
             return idx < smp->size() ? (*smp)[idx] : smp->back();
         };
-        for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
-            const uint64_t r_lo = s + (uint64_t)g0 * 32;
-            const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
-            for (uint64_t c0 = r_lo; c0 < e; c0 += col_chunk) {
-                const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
-                const bool diag = c0 < r_hi;
-                if (smp && !diag &&
-                    range_distance_bound(key_lo(r_lo), key_hi(r_hi), key_lo(c0), key_hi(c1), umi_len,
-                                         bpb) > k) {
-                    pl.n_tasks_pruned++;
-                    continue; // no pair of this tile can be within k
+        // two passes: the tasks on the bucket's diagonal first.  They take about three times as
+        // long as the others (the filter hits of a key-sorted bucket crowd there), and the launch
+        // should end on short tasks.  Within a pass the order is row-tile-major, which shares a
+        // row tile's planes in L2.
+        for (int pass = 0; pass < 2; pass++)
+            for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
+                const uint64_t r_lo = s + (uint64_t)g0 * 32;
+                const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
+                // diagonal chunks of a row tile: those that start before its last row
+                const uint64_t c_begin = pass == 0 ? r_lo : r_lo + (r_hi - r_lo + col_chunk - 1) / col_chunk * col_chunk;
+                const uint64_t c_end = pass == 0 ? std::min<uint64_t>(e, c_begin + (r_hi - r_lo + col_chunk - 1) / col_chunk * col_chunk) : e;
+                for (uint64_t c0 = c_begin; c0 < c_end; c0 += col_chunk) {
+                    const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
+                    const bool diag = c0 < r_hi;
+                    if (smp && !diag &&
+                        range_distance_bound(key_lo(r_lo), key_hi(r_hi), key_lo(c0), key_hi(c1), umi_len,
+                                             bpb) > k) {
+                        pl.n_tasks_pruned++;
+                        continue; // no pair of this tile can be within k
+                    }
+                    list.push_back(BsTask{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
+                                          (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u});
+                    pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
                 }
-                BsTask t{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
-                         (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u};
-                pl.bs_tasks[bb.live ? 4 : (!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1)))]
-                    .push_back(t);
-                pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
             }
-        }
     }
-    // Tasks on a bucket's diagonal take about three times as long as the others (the filter
-    // hits of a key-sorted bucket crowd there): they go first, so that the launch ends on short
-    // tasks.  (stable: the others keep their row-tile-major order, which shares planes in L2)
-    for (auto &v : pl.bs_tasks)
-        std::stable_partition(v.begin(), v.end(), [](const BsTask &t) { return t.diag != 0; });
 }
 
 // Prefix units worth caching for a key-sorted bucket of n entries: the state of the `pu`

@@ -1518,6 +1518,27 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
 // many as the longest chain is long).  Phase 2: lab[c] = smallest set index that reaches set c,
 // propagated along the one-way pairs (rounds <= depth of the DAG).  Then label[v] = lab[comp[v]],
 // the smallest rank that reaches v: what directional.rs:30-54,78-88 removes v under.
+// atomicMin(&arr[idx], val) for the lanes with `todo`, all lanes of the wave calling together.
+// A single word takes ~90 atomics per microsecond, and hooks pile up on the roots of the big
+// trees: the lanes that share the first pending lane's target send one atomic for their
+// minimum, twice; what is left goes one by one.
+__device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uint32_t val, bool todo)
+{
+    for (int pass = 0; pass < 2 && __any(todo); pass++) {
+        const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
+        const uint32_t tgt = (uint32_t)__shfl((int)idx, leader);
+        const bool mine = todo && idx == tgt;
+        uint32_t m = mine ? val : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+        // (a fresh look first: while this wave gathered, others have usually lowered the word)
+        if ((int)(threadIdx.x & 63) == leader && __atomic_load_n(&arr[tgt], __ATOMIC_RELAXED) > m)
+            atomicMin(&arr[tgt], m);
+        todo = todo && !mine;
+    }
+    if (todo) atomicMin(&arr[idx], val);
+}
+
 __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ edges,
                                                       const unsigned long long *counters,
                                                       uint32_t edge_cap, uint32_t *comp,
@@ -1529,7 +1550,8 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ 
     bool any = false;
     constexpr int ILP = 4;
     const uint32_t nth = gridDim.x * blockDim.x;
-    for (uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < E; e0 += ILP * nth) {
+    for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < E; b0 += ILP * nth) { // (wave-uniform trip count)
+        const uint32_t e0 = b0 + threadIdx.x;
         uint2 uv[ILP];
         uint32_t fu[ILP], fv[ILP], gu[ILP], gv[ILP];
 #pragma unroll
@@ -1550,14 +1572,13 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ 
             gv[i] = live ? comp[fv[i]] : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < ILP; i++) {
-            if (fu[i] == fv[i]) continue;
+        for (int i = 0; i < ILP; i++) { // (every lane makes every trip: the shuffles need them all)
+            const bool live = fu[i] != fv[i];
             const uint32_t lo = min(gu[i], gv[i]); // a member of the set, <= everything below
-            if (lo < gu[i]) atomicMin(&comp[fu[i]], lo); // the parent with the larger grandparent
-            if (lo < gv[i]) atomicMin(&comp[fv[i]], lo);
-            if (lo < fu[i]) atomicMin(&comp[uv[i].x & ~SYM_FLAG], lo);
-            if (lo < fv[i]) atomicMin(&comp[uv[i].y], lo);
-            any = true; // parents differ: one of the four moved, or will once the jump has run
+            // the parent with the larger grandparent: one target per pair, often a shared root
+            const bool hook_u = live && lo < gu[i];
+            wave_atomic_min(comp, hook_u ? fu[i] : fv[i], lo, live && (lo < gu[i] || lo < gv[i]));
+            any |= live; // parents differ: one of them moved, or will once the jump has run
         }
     }
     if (any) changed[round] = 1;
@@ -1586,20 +1607,7 @@ __global__ __launch_bounds__(256) void dag_hook_kernel(const uint2 *__restrict__
             todo = lu < lab[cv];
         }
         any |= todo;
-        // Many one-way pairs point into the same few sets (the giant component above all), and a
-        // single word takes ~90 atomics per microsecond: the lanes that share the first pending
-        // lane's target send one atomic for their minimum, twice; what is left goes one by one.
-        for (int pass = 0; pass < 2 && __any(todo); pass++) {
-            const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
-            const uint32_t tgt = (uint32_t)__shfl((int)cv, leader);
-            const bool mine = todo && cv == tgt;
-            uint32_t val = mine ? lu : 0xFFFFFFFFu;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) val = min(val, (uint32_t)__shfl_xor((int)val, off));
-            if ((int)(threadIdx.x & 63) == leader) atomicMin(&lab[tgt], val);
-            todo = todo && !mine;
-        }
-        if (todo) atomicMin(&lab[cv], lu);
+        wave_atomic_min(lab, cv, lu, todo); // many one-way pairs point into the giant component
     }
     if (any) changed[round] = 1;
 }
@@ -1881,8 +1889,12 @@ hipError_t launch_cc_round(const uint2 *edges, const unsigned long long *counter
                            uint32_t *comp, uint32_t n, uint32_t *changed, int round,
                            uint32_t n_edges_hint, hipStream_t s)
 {
-    cc_hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, comp, changed,
-                                                               round);
+    // few enough waves that most of them find a hot root already lowered when they get to it
+    cc_hook_kernel<<<grid_for(n_edges_hint, 256, 512), 256, 0, s>>>(edges, counters, edge_cap, comp,
+                                                                    changed, round);
+    // two jumps per hook: a jump costs a twentieth of a hook and flattens the trees the next
+    // hook walks
+    jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(comp, n, changed, round);
     jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(comp, n, changed, round);
     return hipGetLastError();
 }
