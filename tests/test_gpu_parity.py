@@ -284,6 +284,44 @@ def test_wide_sorted_buckets(L, k, n_raw, n_frac, algo, amf):
         c.close()
 
 
+@pytest.mark.parametrize("L,k", [(12, 2), (11, 1)])
+def test_wide_sorted_bucket_dense_in_neighbours(L, k):
+    """A wide bucket made of 1,000 centres with all their single-substitution variants: in
+    key-sorted order the filter hits crowd into the tiles next to the diagonal, and with k = 2
+    (every pair of a cluster within reach) the hit queue and the edge stage of a block run over:
+    the hits beyond them are checked and written directly."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(77 + L)
+    seen = {}
+    for c in rng.integers(0, 4, (1100, L)):
+        members = [c]
+        for pos in range(L):
+            for b in range(4):
+                if b != c[pos]:
+                    u = c.copy()
+                    u[pos] = b
+                    members.append(u)
+        for u in members:
+            s_ = "".join("ACGT"[x] for x in u)
+            seen[s_] = seen.get(s_, 0) + int(rng.geometric(0.5))
+    umis = list(seen.keys())
+    rng.shuffle(umis)
+    freq = [seen[u] for u in umis]
+    umis, freq, _ = canonical(umis, freq)
+    assert len(umis) >= 32768
+    keys, nm = orc.encode_keys(umis)
+    fr, off = np.array(freq, np.int32), np.array([0, len(umis)], np.uint64)
+    c = umi.Context(0)
+    try:
+        st = check_against_oracle(c, keys, nm, fr, off, L, k)
+        assert st["n_candidates"] > (8 if k == 2 else 1) * len(umis)
+        c.set_option("bs_sorted", 0)
+        st0 = check_against_oracle(c, keys, nm, fr, off, L, k)
+        assert st0["n_edges"] == st["n_edges"]
+    finally:
+        c.close()
+
+
 def test_edge_list_overflow_is_transparent():
     import umi_collapse_rs_amd as umi
     c = umi.Context(0)
