@@ -26,8 +26,8 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_CONFIG2 = (397161.4 + 23819.8) * 1024  # bytes per bs_tab_kernel launch at config 2:
-# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v5_tab.csv
+TRAFFIC_CONFIG2 = (377901.9 + 45912.2) * 1024  # bytes per bs_tab_kernel launch at config 2:
+# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v7.csv
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
 # and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
 # counter over the L'/unit units: 0.5 per unit for K = 0, K+1 per unit for K > 1, and for
