@@ -110,6 +110,70 @@ __global__ __launch_bounds__(256) void k(const uint32_t *in, uint32_t *out, unsi
     out[blockIdx.x * 256 + tid] = acc + hits;
     if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
+// Variant with the tables in LDS (one row group per lane): tab[u][v][lane], 32 KB per block.
+// A column's key stays in a VGPR; two v_bfe/v_lshl_add give the lane's addresses, two
+// ds_read_b32 fetch the entries.  No scalar instruction, no index mode.
+__global__ __launch_bounds__(256) void klds(const uint32_t *in, uint32_t *out, unsigned long long *clk)
+{
+    __shared__ uint32_t ckey[TILE + 16];
+    __shared__ uint32_t tab[2 * 16 * 256];
+    const int tid = threadIdx.x;
+    for (int i = 0; i < 32; i++) tab[i * 256 + tid] = in[(tid * 3 + i * 7) & 8191];
+    uint32_t anyP0 = in[tid & 8191], twoP0 = in[(tid + 9) & 8191];
+    const uint32_t valid = 0xFFFFFFFFu;
+    const uint32_t lane_off = tid * 4;
+    uint32_t acc = 0, hits = 0;
+    unsigned long long t0 = 0, r0 = 0;
+    for (int c0 = 0; c0 < NCOLS; c0 += TILE) {
+        __syncthreads();
+        for (int cc = tid; cc < TILE + 16; cc += 256) ckey[cc] = in[(c0 + cc) & 8191];
+        __syncthreads();
+        if (c0 == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        uint32_t next[4];
+        for (int i = 0; i < 4; i++) next[i] = ckey[i];
+        for (int c = 0; c < TILE; c += 4) {
+            uint32_t key[4], e[4], f[4];
+            for (int i = 0; i < 4; i++) key[i] = next[i];
+            for (int i = 0; i < 4; i++) next[i] = ckey[c + 4 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t a0 = ((key[i] & 15u) << 10) + lane_off;
+                const uint32_t a1 = (((key[i] >> 4) & 15u) << 10) + lane_off + 16 * 1024;
+                e[i] = *(const uint32_t *)((const char *)tab + a0);
+                f[i] = *(const uint32_t *)((const char *)tab + a1);
+            }
+            uint32_t anyhit = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t ta = BITOP3(anyP0, e[i], f[i], 0xe8);
+                anyhit |= BITOP3(twoP0, ta, valid, 0x02);
+            }
+            if (__any(anyhit == 0x12345678u)) hits += anyhit;
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 256 + tid] = acc + hits;
+    if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+void run_lds(uint32_t *in, uint32_t *out, unsigned long long *clk, int blocks_per_cu)
+{
+    const int nblk = 256 * blocks_per_cu;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0)); klds<<<nblk, 256>>>(in, out, clk); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    std::vector<unsigned long long> hc(2 * nblk);
+    CK(hipMemcpy(hc.data(), clk, nblk * 16, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0; for (int b = 0; b < nblk; b++) { cyc += hc[2 * b]; real += hc[2 * b + 1]; }
+    const double ghz = cyc / real * 0.1;
+    const double cols_per_simd = (double)blocks_per_cu * NCOLS;
+    printf("%-44s %d waves/SIMD %7.3f ms %.2f GHz -> %6.1f SIMD-cycles per column of 2048 rows (x2 = %6.1f per 4096)\n",
+           "LDS tables, one group per lane", blocks_per_cu, best, ghz, best * 1e-3 * ghz * 1e9 / cols_per_simd,
+           2 * best * 1e-3 * ghz * 1e9 / cols_per_simd);
+}
+
 template <int MODE> void run(const char *name, uint32_t *in, uint32_t *out, unsigned long long *clk, int blocks_per_cu)
 {
     const int nblk = 256 * blocks_per_cu;
@@ -133,13 +197,14 @@ int main()
     CK(hipMalloc(&in, 8192 * 4)); CK(hipMalloc(&out, (size_t)256 * 4 * 256 * 4)); CK(hipMalloc(&clk, 256 * 4 * 16));
     std::vector<uint32_t> h(8192); for (auto &x : h) x = rand();
     CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    for (int w = 1; w <= 3; w++) {
+    for (int w = 1; w <= 4; w++) {
         run<0>("full", in, out, clk, w);
         run<1>("no hit test", in, out, clk, w);
         run<2>("indices from the loop counter", in, out, clk, w);
         run<3>("no index window", in, out, clk, w);
         run<4>("window only", in, out, clk, w);
         run<6>("three live units (6 tables), tree + merge", in, out, clk, w);
+        run_lds(in, out, clk, w);
     }
     return 0;
 }

@@ -299,10 +299,8 @@ int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, i
     if (k < 0) return fail(UMI_ERR_ARG, "k must be >= 0 (got %d)", k);
     if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
         return fail(UMI_ERR_ARG, "unknown algo %d", algo);
-    for (uint64_t b = 0; b < n_buckets; b++)
-        if (bucket_off[b + 1] < bucket_off[b])
-            return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu",
-                        (unsigned long long)b);
+    // (that the table is monotone is checked while it is copied to its pinned staging buffer,
+    // before anything is launched: Pipeline::upload_and_prep)
     const uint64_t n = n_buckets ? bucket_off[n_buckets] : 0;
     if (n_buckets && bucket_off[0] != 0) return fail(UMI_ERR_ARG, "bucket_off[0] must be 0");
     if (n >= 0x7FFFFFF0ull) // bit 31 of an edge endpoint is a flag
@@ -547,7 +545,16 @@ class Pipeline {
             HIP_TRY(hipHostMalloc((void **)&ctx->h_boff, want * 8));
             ctx->h_boff_cap = want;
         }
-        memcpy(ctx->h_boff, bucket_off, (n_buckets + 1) * 8);
+        { // copy and validate in one pass over the table (0.8 MB for 10^5 positions)
+            uint64_t prev = bucket_off[0];
+            ctx->h_boff[0] = prev;
+            for (uint64_t b = 1; b <= n_buckets; b++) {
+                const uint64_t v = bucket_off[b];
+                if (v < prev)
+                    return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)(b - 1));
+                ctx->h_boff[b] = prev = v;
+            }
+        }
         HIP_TRY(hipMemcpyAsync(ctx->boff.p, ctx->h_boff, (n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
         if (mode == MODE_ADJACENCY && need_pairs) {
             HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
