@@ -78,6 +78,9 @@ struct Plan {
     // [4] table-variant tiles (key-sorted, 32-bit keys, 2 live units)
     std::vector<BsTask> bs_tasks[5];
     std::vector<PlaneTask> plane_tasks;
+    // entries of the buckets the fused kernel does not take, in chunks: what prep and finalize
+    // work on (empty for a batch of small positions)
+    std::vector<RangeTask> ranges;
     struct BsBucket {
         uint64_t s, e, plane_off;
         uint32_t ngroups;
@@ -125,7 +128,7 @@ struct umi_ctx {
     bool two_phase = true; // directional collapse: components of the symmetric pairs, then the DAG
     // workspace
     DevBuf fkey, thr, label, lab, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
-    DevBuf bs_tasks, plane_tasks, planes;
+    DevBuf bs_tasks, plane_tasks, planes, ranges;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
     Plan plan;
@@ -137,7 +140,7 @@ struct umi_ctx {
     size_t h_tasks_cap = 0;
     unsigned long long *h_counters = nullptr; // pinned
     uint32_t *h_changed = nullptr;            // pinned
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -242,6 +245,13 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
                 Plan &pl)
 {
     pl.n_fused = 0;
+    pl.ranges.clear();
+    uint64_t run_s = 0, run_e = 0; // current run of entries the fused kernel does not take
+    auto close_run = [&]() {
+        for (uint64_t q = run_s; q < run_e; q += RANGE_CHUNK)
+            pl.ranges.push_back({(uint32_t)q, (uint32_t)std::min<uint64_t>(run_e, q + RANGE_CHUNK)});
+        run_s = run_e = 0;
+    };
     pl.small_tasks.clear();
     pl.big_tasks.clear();
     for (auto &v : pl.bs_tasks) v.clear();
@@ -254,6 +264,13 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
         const uint64_t n = e - s;
         pl.max_bucket = std::max(pl.max_bucket, n);
+        if (n > fused_max) { // prep and finalize are this bucket's (runs of neighbours merge)
+            if (run_e != s) {
+                close_run();
+                run_s = s;
+            }
+            run_e = e;
+        }
         if (n < 2) continue;
         pl.n_pairs += n * (n - 1) / 2;
         if (n <= fused_max) {
@@ -287,6 +304,7 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             }
         }
     }
+    close_run();
 }
 
 int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
@@ -419,7 +437,7 @@ class Pipeline {
     const uint32_t part, n_parts; // n_parts > 1: evaluate only every n_parts-th tile task, stop
                                   // after the pair kernels (multi-GPU split of one call's pairs)
     uint64_t task_counter = 0;    // running index over all tile tasks, for that split
-    bool prune = false, drained = false;
+    bool prune = false, drained = false, fused_ran = false;
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
@@ -431,11 +449,14 @@ class Pipeline {
     int run_stages()
     {
         int rc;
-        // prep needs nothing from the plan: it is enqueued first, and the host walks the bucket
-        // table (tile tasks, pair counts) while the bucket table uploads and prep runs
+        // The fused kernel needs nothing from the plan (it walks the bucket table itself and does
+        // everything for its buckets): it is enqueued first, and the host walks the table -- tile
+        // tasks, pair counts, the entry ranges left for prep and finalize -- while it runs.
         if ((rc = reserve_core())) return rc;
-        if ((rc = upload_and_prep())) return rc;
+        if ((rc = upload_table())) return rc;
+        if ((rc = fused_stage())) return rc;
         if ((rc = plan_and_upload_tasks())) return rc;
+        if ((rc = prep_stage())) return rc;
         if (prune) {
             if ((rc = prune_stage())) return rc;
         } else {
@@ -530,8 +551,8 @@ class Pipeline {
         return UMI_OK;
     }
 
-    // counters, bucket table; filter keys / thresholds / labels
-    int upload_and_prep()
+    // counters, bucket table
+    int upload_table()
     {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
@@ -560,7 +581,33 @@ class Pipeline {
             HIP_TRY(hipMemsetAsync(ctx->status.p, 0, n, s));
             HIP_TRY(hipMemsetAsync(ctx->blocked.p, 0, n, s));
         }
-        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, n, umi_len,
+        return UMI_OK;
+    }
+
+    // every bucket of at most fused_max entries, start to finish (its time counts as pair time)
+    int fused_stage()
+    {
+        if (fused_max < 1 || n_buckets == 0) return UMI_OK;
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[5], s));
+        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, percentage, ctx->boff.as<uint64_t>(),
+                                     (uint32_t)n_buckets, fused_max, ctx->label.as<uint32_t>(), d_kept,
+                                     d_root, k, umi_len, ctx->fused_sliced, mode, adj_max_freq, d_cnt, s));
+        if (prof) HIP_TRY(hipEventRecord(ctx->ev[6], s));
+        fused_ran = true;
+        st.n_pair_launches += 1;
+        return UMI_OK;
+    }
+
+    // filter keys / thresholds / labels / contract check of the entries the fused kernel left
+    int prep_stage()
+    {
+        int rc;
+        if ((rc = ctx->ranges.reserve(std::max<size_t>(1, pl.ranges.size()) * sizeof(RangeTask)))) return rc;
+        if (!pl.ranges.empty())
+            HIP_TRY(hipMemcpyAsync(ctx->ranges.p, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask),
+                                   hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets,
+                            ctx->ranges.as<RangeTask>(), (uint32_t)pl.ranges.size(), n, fused_max, umi_len,
                             percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
                             ctx->label.as<uint32_t>(), d_cnt, s));
         return UMI_OK;
@@ -683,14 +730,6 @@ class Pipeline {
     // (redone once with a larger list if it overflowed: the exact count is known by then)
     int pair_stage()
     {
-        if (pl.n_fused) {
-            HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, ctx->thr.as<int32_t>(),
-                                         ctx->boff.as<uint64_t>(), (uint32_t)n_buckets, fused_max,
-                                         ctx->label.as<uint32_t>(), ctx->status.as<uint8_t>(), k,
-                                         umi_len, ctx->fused_sliced, mode,
-                                         adj_max_freq, s));
-            st.n_pair_launches += 1;
-        }
         if (!(need_pairs && n_tasks)) {
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             return UMI_OK;
@@ -780,7 +819,8 @@ class Pipeline {
             st.n_rounds = (uint32_t)rounds;
         }
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
-        HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+        HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), ctx->ranges.as<RangeTask>(), (uint32_t)pl.ranges.size(), n,
+                                d_kept, d_root, d_cnt, s));
         return UMI_OK;
     }
 
@@ -803,7 +843,8 @@ class Pipeline {
         }
         st.n_rounds = (uint32_t)iters;
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
-        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), ctx->ranges.as<RangeTask>(),
+                                    (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
         return UMI_OK;
     }
 
@@ -818,6 +859,12 @@ class Pipeline {
             hipEvent_t *ev = ctx->ev;
             HIP_TRY(hipEventElapsedTime(&st.ms_prep, ev[0], ev[1]));
             HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ev[1], ev[2]));
+            if (fused_ran) { // the fused kernel ran inside the prep window
+                float ms_fused = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms_fused, ev[5], ev[6]));
+                st.ms_prep -= ms_fused;
+                st.ms_pairs += ms_fused;
+            }
             HIP_TRY(hipEventElapsedTime(&st.ms_collapse, ev[2], ev[3]));
             HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
             HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
@@ -880,7 +927,7 @@ class EdgeCollapse {
                 if ((rc = directional_labels(ctx, d_edges, d_cnt, n_edges, n_edges, n, s, rounds))) return rc;
                 st.n_rounds = (uint32_t)rounds;
             }
-            HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+            HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), nullptr, 0, n, d_kept, d_root, d_cnt, s));
         } else {
             uint8_t *d_status = ctx->status.as<uint8_t>(), *d_blocked = ctx->blocked.as<uint8_t>();
             HIP_TRY(hipMemsetAsync(d_status, 0, n, s));
@@ -898,7 +945,7 @@ class EdgeCollapse {
                 if (iters > MAX_ROUNDS) return fail(UMI_ERR_HIP, "adjacency collapse diverged");
             }
             st.n_rounds = (uint32_t)iters;
-            HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), n, d_kept, d_root, d_cnt, s));
+            HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), nullptr, 0, n, d_kept, d_root, d_cnt, s));
         }
         HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, s));
@@ -952,7 +999,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
         err = hipHostMalloc((void **)&ctx->h_counters, CNT_COUNT * sizeof(unsigned long long));
     if (err == hipSuccess)
         err = hipHostMalloc((void **)&ctx->h_changed, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1));
-    for (int i = 0; i < 6 && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 8 && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
     if (err != hipSuccess) {
         umi_ctx_destroy(ctx);
         return fail(UMI_ERR_HIP, "context setup failed: %s", hipGetErrorString(err));
@@ -965,7 +1012,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->fkey_sorted, &ctx->perm,
+    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->ranges, &ctx->fkey_sorted, &ctx->perm,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
@@ -976,7 +1023,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 8; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -48,6 +48,12 @@ struct BsTask {
     uint32_t pad;
 };
 
+// A run of entries for the per-entry kernels (prep, finalize): one block each.
+struct RangeTask {
+    uint32_t start, end;
+};
+constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
+
 constexpr int BS_TAB_G2 = 2;    // row groups per lane of the table variant with 2 live units
 constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
@@ -89,8 +95,9 @@ constexpr int BIG_ROWS = BIG_THREADS * BIG_RPT;
 constexpr int COL_TILE = 1024; // column keys staged in LDS per step
 
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                       const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len,
-                       float percentage, bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
+                       uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
+                       bool key32, void *fkey, int32_t *thr, uint32_t *label,
                        unsigned long long *counters, hipStream_t s);
 
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);
@@ -127,9 +134,10 @@ hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32
 // walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[]).
 // sliced: use the bit-sliced body when k <= 3
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                                const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
-                                int umi_len, bool sliced, int mode, int32_t adj_max_freq, hipStream_t s);
+                                float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
+                                uint32_t fused_max, uint32_t *label, uint8_t *kept, uint32_t *root,
+                                int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
+                                unsigned long long *counters, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a
 // no-op on the device when round r-1 changed nothing.
@@ -148,16 +156,16 @@ hipError_t launch_dag_round(const uint2 *edges, const unsigned long long *counte
                             int round, uint32_t n_edges_hint, hipStream_t s);
 hipError_t launch_map_labels(uint32_t *comp, const uint32_t *lab, uint32_t n, hipStream_t s);
 
-hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
-                           unsigned long long *counters, hipStream_t s);
+hipError_t launch_finalize(const uint32_t *label, const RangeTask *ranges, uint32_t n_ranges, uint32_t n,
+                           uint8_t *kept, uint32_t *root, unsigned long long *counters, hipStream_t s);
 
 // adjacency collapse with max_freq > 0 (greedy in rank order): one iteration
 hipError_t launch_adj_iter(const uint2 *edges, const unsigned long long *counters,
                            uint32_t edge_cap, uint8_t *status, uint8_t *blocked, uint32_t *label,
                            uint32_t n, unsigned long long *counters_rw, uint32_t n_edges_hint,
                            hipStream_t s);
-hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, uint32_t n,
-                               uint8_t *kept, uint32_t *root, unsigned long long *counters,
-                               hipStream_t s);
+hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, const RangeTask *ranges,
+                               uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
+                               unsigned long long *counters, hipStream_t s);
 
 } // namespace umihip

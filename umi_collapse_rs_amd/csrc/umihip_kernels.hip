@@ -64,19 +64,33 @@ __device__ __forceinline__ void block_count_add(unsigned int cnt, unsigned long 
     __syncthreads(); // part[] may be reused by a second call
 }
 
+// Entry ranges a per-entry kernel works on: block b takes ranges[b] (<= RANGE_CHUNK entries);
+// ranges == nullptr: all n entries, grid-stride.  The fused small-bucket kernel validates,
+// thresholds and finalises its own buckets, so on a batch of 10^5 small positions these
+// kernels have nothing to do.
+template <class F>
+__device__ __forceinline__ void for_entries(const RangeTask *__restrict__ ranges, uint32_t n, F f)
+{
+    if (ranges) {
+        const RangeTask r = ranges[blockIdx.x];
+        for (uint32_t i = r.start + threadIdx.x; i < r.end; i += blockDim.x) f(i);
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) f(i);
+    }
+}
+
 __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ keys,
                                                    const uint64_t *__restrict__ nmask,
                                                    const int32_t *__restrict__ freq,
-                                                   const uint64_t *__restrict__ bucket_off,
-                                                   uint64_t n_buckets, uint32_t n, int umi_len,
-                                                   float percentage, int key32,
+                                                   const RangeTask *__restrict__ ranges, uint32_t n,
+                                                   int umi_len, float percentage, int key32,
                                                    void *__restrict__ fkey,
                                                    int32_t *__restrict__ thr,
                                                    uint32_t *__restrict__ label,
                                                    unsigned long long *__restrict__ counters)
 {
     unsigned int bad = 0, rises = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for_entries(ranges, n, [&](uint32_t i) {
         const uint64_t key = keys[i];
         const uint64_t nm = nmask ? nmask[i] : 0ull;
         const int32_t f = freq[i];
@@ -93,26 +107,28 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
             ((uint64_t *)fkey)[i] = k3;
         }
         // contract check: freq >= 1 and non-increasing inside a bucket.  A rise is legal only
-        // at the first entry of a bucket: rises are counted here, rises at bucket starts by
-        // bucket_rise_kernel, and the host requires the two counts to agree (a per-entry
-        // search of the bucket table costs a chain of dependent loads in nearly every wave).
+        // at the first entry of a bucket: rises are counted here, rises at the starts of the
+        // same buckets by bucket_rise_kernel, and the host requires the two counts to agree
+        // (a per-entry search of the bucket table costs a chain of dependent loads in nearly
+        // every wave).
         bad += f < 1 ? 1u : 0u;
         rises += (i > 0 && f > freq[i - 1]) ? 1u : 0u;
-    }
+    });
     block_count_add(bad, &counters[CNT_ERROR]);
     block_count_add(rises, &counters[CNT_RISES]);
 }
 
+// rises at the first entry of the buckets the per-entry kernels cover (larger than min_size_m1)
 __global__ __launch_bounds__(256) void bucket_rise_kernel(const int32_t *__restrict__ freq,
                                                           const uint64_t *__restrict__ bucket_off,
-                                                          uint64_t n_buckets,
+                                                          uint64_t n_buckets, uint32_t fused_max,
                                                           unsigned long long *__restrict__ counters)
 {
     unsigned int rises = 0;
     for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets;
          b += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t s = bucket_off[b];
-        if (s > 0 && s < bucket_off[b + 1]) rises += freq[s] > freq[s - 1] ? 1u : 0u;
+        const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
+        if (s > 0 && s < e && e - s > fused_max) rises += freq[s] > freq[s - 1] ? 1u : 0u;
     }
     block_count_add(rises, &counters[CNT_START_RISES]);
 }
@@ -1067,14 +1083,62 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
 }
 
 // one bucket [start, start + n), n <= 64 * RL, by the calling wave
+// what one fused bucket hands back: contract violations seen, survivors written
+struct FusedCounts {
+    unsigned int bad, kept;
+};
+
+// contract check of a fused bucket (prep_kernel does it for the others): freq >= 1 and
+// non-increasing from row to row; fr[s] of the rows past n is a sentinel and not looked at
+template <int RL>
+__device__ __forceinline__ unsigned int fused_bad_rows(const int32_t (&fr)[RL], int n)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned int bad = 0;
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int row = lane + 64 * s;
+        int32_t prev = __shfl_up(fr[s], 1);
+        if (lane == 0) prev = s == 0 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(fr[0], 63);
+        if (row < n) bad += (fr[s] < 1 ? 1u : 0u) + ((row > 0 && fr[s] > prev) ? 1u : 0u);
+    }
+    return bad;
+}
+
+// label, kept mask and root of a fused bucket's rows (what finalize_kernel / adj_finalize_kernel
+// write for the others); returns the survivors among this lane's rows
+template <int RL, int MODE>
+__device__ __forceinline__ unsigned int fused_write_out(uint32_t start, int n, const uint32_t (&lab)[RL],
+                                                        const uint32_t (&alive)[RL],
+                                                        uint32_t *__restrict__ label,
+                                                        uint8_t *__restrict__ kept,
+                                                        uint32_t *__restrict__ root)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned int n_kept = 0;
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int row = lane + 64 * s;
+        if (row < n) {
+            const bool kp = MODE == MODE_DIRECTIONAL ? lab[s] == (uint32_t)row : alive[s] != 0u;
+            label[start + row] = start + lab[s];
+            kept[start + row] = kp ? 1 : 0;
+            if (root) root[start + row] = (MODE != MODE_DIRECTIONAL && kp) ? start + row : start + lab[s];
+            n_kept += kp ? 1u : 0u;
+        }
+    }
+    return n_kept;
+}
+
 template <int RL, bool HAS_N, int MODE>
-__device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ keys,
-                                                  const uint64_t *__restrict__ nmask,
-                                                  const int32_t *__restrict__ freq,
-                                                  const int32_t *__restrict__ thr, uint32_t start,
-                                                  int n, uint32_t *__restrict__ label,
-                                                  uint8_t *__restrict__ status, int k,
-                                                  int32_t adj_max_freq)
+__device__ __forceinline__ FusedCounts small_bucket_body(const uint64_t *__restrict__ keys,
+                                                         const uint64_t *__restrict__ nmask,
+                                                         const int32_t *__restrict__ freq,
+                                                         float percentage, uint32_t start, int n,
+                                                         uint32_t *__restrict__ label,
+                                                         uint8_t *__restrict__ kept,
+                                                         uint32_t *__restrict__ root, int k,
+                                                         int32_t adj_max_freq)
 {
     const int lane = threadIdx.x & 63;
     constexpr int H = 2 * RL; // the bucket's entries in halves of 32: half h = entries 32h..32h+31
@@ -1087,7 +1151,7 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
         key[s] = in_range ? keys[start + r] : 0ull;
         nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
         fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
-        th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+        th[s] = in_range ? threshold_of(percentage, fr[s]) : (-0x7FFFFFFF - 1);
     }
     // in[s][h]: bit jj set <=> entry j = 32h+jj may remove row (lane + 64s)
     uint32_t in[RL][H];
@@ -1120,9 +1184,12 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
             }
         }
     }
-    uint32_t lab[RL];
+    uint32_t lab[RL], alive[RL];
 #pragma unroll
-    for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+    for (int s = 0; s < RL; s++) {
+        lab[s] = (uint32_t)(lane + 64 * s);
+        alive[s] = 0u;
+    }
     if (MODE == MODE_DIRECTIONAL) {
         bool changed;
         do { // Gauss-Seidel sweeps in rank order until no label moves
@@ -1143,11 +1210,7 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
 #pragma unroll
             for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
         } while (__any(changed));
-#pragma unroll
-        for (int s = 0; s < RL; s++)
-            if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
     } else {
-        uint32_t alive[RL];
 #pragma unroll
         for (int s = 0; s < RL; s++) alive[s] = 1u;
 #pragma unroll
@@ -1166,13 +1229,11 @@ __device__ __forceinline__ void small_bucket_body(const uint64_t *__restrict__ k
                 }
             }
         }
-#pragma unroll
-        for (int s = 0; s < RL; s++)
-            if (lane + 64 * s < n) {
-                label[start + lane + 64 * s] = start + lab[s];
-                status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
-            }
     }
+    FusedCounts out;
+    out.bad = fused_bad_rows<RL>(fr, n);
+    out.kept = fused_write_out<RL, MODE>(start, n, lab, alive, label, kept, root);
+    return out;
 }
 
 // ---- the same, with the distances bit-sliced over the bucket's columns -------------
@@ -1193,13 +1254,14 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 }
 
 template <int RL, bool HAS_N, int MODE, int K>
-__device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict__ keys,
-                                                     const uint64_t *__restrict__ nmask,
-                                                     const int32_t *__restrict__ freq,
-                                                     const int32_t *__restrict__ thr, uint32_t start,
-                                                     int n, int umi_len, uint32_t *__restrict__ label,
-                                                     uint8_t *__restrict__ status,
-                                                     int32_t adj_max_freq)
+__device__ __forceinline__ FusedCounts small_bucket_body_bs(const uint64_t *__restrict__ keys,
+                                                            const uint64_t *__restrict__ nmask,
+                                                            const int32_t *__restrict__ freq,
+                                                            float percentage, uint32_t start, int n,
+                                                            int umi_len, uint32_t *__restrict__ label,
+                                                            uint8_t *__restrict__ kept,
+                                                            uint32_t *__restrict__ root,
+                                                            int32_t adj_max_freq)
 {
     const int lane = threadIdx.x & 63;
     constexpr int H = 2 * RL; // column halves of 32
@@ -1213,7 +1275,7 @@ __device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict_
         nm[s] = (HAS_N && in_range) ? nmask[start + r] : 0ull;
         fold[s] = key[s] & ~nm[s]; // N folded onto A: the sliced distance never exceeds the exact one
         fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
-        th[s] = in_range ? thr[start + r] : (-0x7FFFFFFF - 1);
+        th[s] = in_range ? threshold_of(percentage, fr[s]) : (-0x7FFFFFFF - 1);
     }
     // cnt[s][h][l]: columns of half h at which row (lane + 64 s) has more than l mismatches so far
     uint32_t cnt[RL][H][K + 1];
@@ -1349,9 +1411,12 @@ __device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict_
         for (int s = 0; s < RL; s++) v |= in[s][h];
         act[h] = __builtin_amdgcn_readfirstlane(wave_or(v));
     }
-    uint32_t lab[RL];
+    uint32_t lab[RL], alive[RL];
 #pragma unroll
-    for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+    for (int s = 0; s < RL; s++) {
+        lab[s] = (uint32_t)(lane + 64 * s);
+        alive[s] = 0u;
+    }
     if (MODE == MODE_DIRECTIONAL) {
         bool changed;
         do { // Gauss-Seidel sweeps in rank order over the active sources until no label moves
@@ -1374,11 +1439,7 @@ __device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict_
 #pragma unroll
             for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
         } while (__any(changed));
-#pragma unroll
-        for (int s = 0; s < RL; s++)
-            if (lane + 64 * s < n) label[start + lane + 64 * s] = start + lab[s];
     } else {
-        uint32_t alive[RL];
 #pragma unroll
         for (int s = 0; s < RL; s++) alive[s] = 1u;
 #pragma unroll
@@ -1399,13 +1460,11 @@ __device__ __forceinline__ void small_bucket_body_bs(const uint64_t *__restrict_
                 }
             }
         }
-#pragma unroll
-        for (int s = 0; s < RL; s++)
-            if (lane + 64 * s < n) {
-                label[start + lane + 64 * s] = start + lab[s];
-                status[start + lane + 64 * s] = alive[s] ? (uint8_t)1 : (uint8_t)2;
-            }
     }
+    FusedCounts out;
+    out.bad = fused_bad_rows<RL>(fr, n);
+    out.kept = fused_write_out<RL, MODE>(start, n, lab, alive, label, kept, root);
+    return out;
 }
 
 // Walks the bucket table itself (no task list to build or upload): wave w takes buckets
@@ -1416,37 +1475,56 @@ template <bool HAS_N, int MODE, int KB>
 __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
                                                            const uint64_t *__restrict__ nmask,
                                                            const int32_t *__restrict__ freq,
-                                                           const int32_t *__restrict__ thr,
+                                                           float percentage,
                                                            const uint64_t *__restrict__ bucket_off,
                                                            uint32_t n_buckets, uint32_t fused_max,
                                                            uint32_t *__restrict__ label,
-                                                           uint8_t *__restrict__ status, int k,
-                                                           int umi_len, int32_t adj_max_freq)
+                                                           uint8_t *__restrict__ kept,
+                                                           uint32_t *__restrict__ root, int k,
+                                                           int umi_len, int32_t adj_max_freq,
+                                                           unsigned long long *__restrict__ counters)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    unsigned int bad = 0, n_kept = 0; // per lane; summed over the block at the end
     for (uint32_t b = wave; b < n_buckets; b += n_waves) {
         const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b]);
         const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b + 1]);
         const uint32_t n = end - start;
-        if (n < 2 || n > fused_max) continue;
+        if (n == 0 || n > fused_max) continue;
+        if (n == 1) { // a position with one UMI: it survives
+            if (lane == 0) {
+                label[start] = start;
+                kept[start] = 1;
+                if (root) root[start] = start;
+                bad += freq[start] < 1 ? 1u : 0u;
+                n_kept += 1;
+            }
+            continue;
+        }
+        FusedCounts c;
         if (KB >= 0) {
             constexpr int K = KB >= 0 ? KB : 0;
             if (n <= 64)
-                small_bucket_body_bs<1, HAS_N, MODE, K>(keys, nmask, freq, thr, start, (int)n, umi_len,
-                                                        label, status, adj_max_freq);
+                c = small_bucket_body_bs<1, HAS_N, MODE, K>(keys, nmask, freq, percentage, start, (int)n,
+                                                            umi_len, label, kept, root, adj_max_freq);
             else
-                small_bucket_body_bs<2, HAS_N, MODE, K>(keys, nmask, freq, thr, start, (int)n, umi_len,
-                                                        label, status, adj_max_freq);
+                c = small_bucket_body_bs<2, HAS_N, MODE, K>(keys, nmask, freq, percentage, start, (int)n,
+                                                            umi_len, label, kept, root, adj_max_freq);
         } else {
             if (n <= 64)
-                small_bucket_body<1, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
-                                                  adj_max_freq);
+                c = small_bucket_body<1, HAS_N, MODE>(keys, nmask, freq, percentage, start, (int)n, label,
+                                                      kept, root, k, adj_max_freq);
             else
-                small_bucket_body<2, HAS_N, MODE>(keys, nmask, freq, thr, start, (int)n, label, status, k,
-                                                  adj_max_freq);
+                c = small_bucket_body<2, HAS_N, MODE>(keys, nmask, freq, percentage, start, (int)n, label,
+                                                      kept, root, k, adj_max_freq);
         }
+        bad += c.bad;
+        n_kept += c.kept;
     }
+    block_count_add(bad, &counters[CNT_ERROR]);
+    block_count_add(n_kept, &counters[CNT_KEPT]);
 }
 
 // ---- collapse: directed min-rank label propagation ---------------------------
@@ -1620,18 +1698,19 @@ __global__ __launch_bounds__(256) void map_label_kernel(uint32_t *comp, const ui
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ label,
-                                                       uint32_t n, uint8_t *__restrict__ kept,
+                                                       const RangeTask *__restrict__ ranges, uint32_t n,
+                                                       uint8_t *__restrict__ kept,
                                                        uint32_t *__restrict__ root,
                                                        unsigned long long *counters)
 {
     unsigned int cnt = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for_entries(ranges, n, [&](uint32_t i) {
         const uint32_t l = label[i];
         const bool kp = l == i;
         kept[i] = kp ? 1 : 0;
         if (root) root[i] = l;
         cnt += kp ? 1u : 0u;
-    }
+    });
     block_count_add(cnt, &counters[CNT_KEPT]);
 }
 
@@ -1673,17 +1752,18 @@ __global__ __launch_bounds__(256) void adj_promote_kernel(uint8_t *status, uint8
 
 __global__ __launch_bounds__(256) void adj_finalize_kernel(const uint8_t *__restrict__ status,
                                                            const uint32_t *__restrict__ label,
-                                                           uint32_t n, uint8_t *__restrict__ kept,
+                                                           const RangeTask *__restrict__ ranges, uint32_t n,
+                                                           uint8_t *__restrict__ kept,
                                                            uint32_t *__restrict__ root,
                                                            unsigned long long *counters)
 {
     unsigned int cnt = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for_entries(ranges, n, [&](uint32_t i) {
         const bool kp = status[i] == ST_ROOT;
         kept[i] = kp ? 1 : 0;
         if (root) root[i] = kp ? i : label[i];
         cnt += kp ? 1u : 0u;
-    }
+    });
     block_count_add(cnt, &counters[CNT_KEPT]);
 }
 
@@ -1697,17 +1777,19 @@ inline uint32_t grid_for(uint64_t work, int block, uint32_t cap = 2048)
 
 } // namespace
 
+// ranges == nullptr: all n entries; else n_ranges chunks of entries (one block each)
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                       const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n, int umi_len,
-                       float percentage, bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
+                       uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
+                       bool key32, void *fkey, int32_t *thr, uint32_t *label,
                        unsigned long long *counters, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    prep_kernel<<<grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, bucket_off, n_buckets, n,
-                                                 umi_len, percentage, key32 ? 1 : 0, fkey, thr,
-                                                 label, counters);
+    if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
+    prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
+                                                                     percentage, key32 ? 1 : 0, fkey, thr,
+                                                                     label, counters);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
-                                                                     counters);
+                                                                     ranges ? fused_max : 0u, counters);
     return hipGetLastError();
 }
 
@@ -1823,14 +1905,15 @@ hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool 
 namespace {
 template <bool HAS_N, int MODE>
 void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_t *nmask,
-                    const int32_t *freq, const int32_t *thr, const uint64_t *bucket_off,
-                    uint32_t n_buckets, uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
-                    int umi_len, int32_t adj_max_freq, hipStream_t s)
+                    const int32_t *freq, float percentage, const uint64_t *bucket_off,
+                    uint32_t n_buckets, uint32_t fused_max, uint32_t *label, uint8_t *kept,
+                    uint32_t *root, int k, int umi_len, int32_t adj_max_freq,
+                    unsigned long long *counters, hipStream_t s)
 {
-#define UMI_LAUNCH_SMALL(KB)                                                                      \
-    small_bucket_kernel<HAS_N, MODE, KB><<<blocks, 256, 0, s>>>(keys, nmask, freq, thr, bucket_off, \
-                                                                n_buckets, fused_max, label, status, \
-                                                                k, umi_len, adj_max_freq)
+#define UMI_LAUNCH_SMALL(KB)                                                                          \
+    small_bucket_kernel<HAS_N, MODE, KB><<<blocks, 256, 0, s>>>(keys, nmask, freq, percentage, bucket_off, \
+                                                                n_buckets, fused_max, label, kept, root, k, \
+                                                                umi_len, adj_max_freq, counters)
     switch (kb) {
     case 0: UMI_LAUNCH_SMALL(0); break;
     case 1: UMI_LAUNCH_SMALL(1); break;
@@ -1842,20 +1925,23 @@ void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_
 }
 } // namespace
 
+// Every bucket of at most fused_max entries, start to finish: contract check, thresholds,
+// label, kept mask, root, survivor count.
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                                const int32_t *thr, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *status, int k,
-                                int umi_len, bool sliced, int mode, int32_t adj_max_freq, hipStream_t s)
+                                float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
+                                uint32_t fused_max, uint32_t *label, uint8_t *kept, uint32_t *root,
+                                int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
+                                unsigned long long *counters, hipStream_t s)
 {
-    if (n_buckets == 0 || fused_max < 2) return hipSuccess;
+    if (n_buckets == 0 || fused_max < 1) return hipSuccess;
     const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, 256 * 8);
     const int kb = (sliced && k >= 0 && k <= 3) ? k : -1;
     if (mode == MODE_DIRECTIONAL) {
-        if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
-        else launch_small_k<false, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
+        if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        else launch_small_k<false, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
     } else {
-        if (nmask) launch_small_k<true, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
-        else launch_small_k<false, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, thr, bucket_off, n_buckets, fused_max, label, status, k, umi_len, adj_max_freq, s);
+        if (nmask) launch_small_k<true, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        else launch_small_k<false, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
     }
     return hipGetLastError();
 }
@@ -1916,11 +2002,12 @@ hipError_t launch_map_labels(uint32_t *comp, const uint32_t *lab, uint32_t n, hi
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const uint32_t *label, uint32_t n, uint8_t *kept, uint32_t *root,
-                           unsigned long long *counters, hipStream_t s)
+hipError_t launch_finalize(const uint32_t *label, const RangeTask *ranges, uint32_t n_ranges, uint32_t n,
+                           uint8_t *kept, uint32_t *root, unsigned long long *counters, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    finalize_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(label, n, kept, root, counters);
+    if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
+    finalize_kernel<<<ranges ? n_ranges : grid_for(n, 1024, 1024), 256, 0, s>>>(label, ranges, n, kept, root,
+                                                                                counters);
     return hipGetLastError();
 }
 
@@ -1935,12 +2022,13 @@ hipError_t launch_adj_iter(const uint2 *edges, const unsigned long long *counter
     return hipGetLastError();
 }
 
-hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, uint32_t n,
-                               uint8_t *kept, uint32_t *root, unsigned long long *counters,
-                               hipStream_t s)
+hipError_t launch_adj_finalize(const uint8_t *status, const uint32_t *label, const RangeTask *ranges,
+                               uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
+                               unsigned long long *counters, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    adj_finalize_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(status, label, n, kept, root, counters);
+    if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
+    adj_finalize_kernel<<<ranges ? n_ranges : grid_for(n, 1024, 1024), 256, 0, s>>>(status, label, ranges, n,
+                                                                                    kept, root, counters);
     return hipGetLastError();
 }
 
