@@ -130,8 +130,9 @@ hipError_t sort_bucket(const void *fkey, bool key32, int key_bits, uint32_t star
 hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32_t n, uint64_t *out,
                        hipStream_t s);
 
-// all-pairs + collapse of whole small buckets (2..fused_max entries), one wave per bucket;
-// walks bucket_off (device copy) itself and writes label[] (and, in adjacency mode, status[]).
+// Everything for the buckets of 1..fused_max entries, one wave per bucket: contract check,
+// thresholds, all pairs, collapse, label[], kept[], root[] (may be NULL), survivors and
+// violations into counters[].  Walks bucket_off (device copy) itself.
 // sliced: use the bit-sliced body when k <= 3
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 float percentage, const uint64_t *bucket_off, uint32_t n_buckets,

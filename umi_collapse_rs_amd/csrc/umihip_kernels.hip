@@ -1073,8 +1073,9 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
 // (bitset.rs:85-87) decides each pair, the permitted in-edges of a row are kept as bit
 // masks in registers, and the collapse runs in-wave: Gauss-Seidel min-label sweeps in
 // rank order for directional (directional.rs:30-54,78-88), the sequential root loop for
-// adjacency (adjacency.rs:52-60).  No LDS, no atomics, no edge list: 24 B/entry in,
-// 4 B/entry out, so this kernel streams at whatever HBM/launch latency allows.
+// adjacency (adjacency.rs:52-60).  No LDS, no edge list.  The kernel also does for its buckets
+// what prep_kernel and finalize_kernel do for the others (contract check, thresholds, kept
+// mask, root, survivor count): a batch of small positions is this one launch.
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
 {
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
