@@ -343,6 +343,21 @@ __device__ __forceinline__ uint32_t bit_of(uint64_t k3, int b)
     return pos < 63 ? (uint32_t)(k3 >> pos) & 1u : 0u; // base 21 is padding (umi_len <= 21)
 }
 
+// Bases in which two filter keys differ (2-bit codes, N folded onto A: never above the exact
+// distance).  The unit-level filter lets through pairs that differ in two bases of one unit:
+// this count, from two neighbouring reads of the tile's own key array, drops them before the
+// exact check gathers keys, freq and thresholds through the permutation.
+__device__ __forceinline__ int filter_key_distance(uint32_t a, uint32_t b)
+{
+    const uint32_t x = a ^ b;
+    return __builtin_popcount((x | (x >> 1)) & 0x55555555u);
+}
+__device__ __forceinline__ int filter_key_distance(uint64_t a, uint64_t b)
+{ // 3 bits per base (the third is 0 in a folded key)
+    const uint64_t x = a ^ b;
+    return __builtin_popcountll((x | (x >> 1) | (x >> 2)) & 0x1249249249249249ull);
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(64) void build_planes_kernel(const KeyT *__restrict__ fkey,
                                                           const PlaneTask *__restrict__ tasks,
@@ -697,10 +712,12 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
         const uint32_t queued = hitq_count; // the same for every thread: stable between the barriers
         if (queued >= HITQ / 2 || c0 + BS_COL_TILE >= col1) {
             const uint32_t nq = min(queued, HITQ);
-            for (uint32_t i = tid; i < nq; i += THREADS)
+            for (uint32_t i = tid; i < nq; i += THREADS) {
+                const uint2 h = hitq[i];
+                if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue; // two bases of one unit
                 verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x,
-                            hitq[i].y, a.perm);
+                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, h.x, h.y, a.perm);
+            }
             __syncthreads();
             if (tid == 0) hitq_count = 0;
             flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, true);
@@ -1053,10 +1070,12 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
         const uint32_t queued = hitq_count; // the same for every thread: stable between the barriers
         if (queued >= HITQ / 2 || c0 + TILE >= col1) {
             const uint32_t nq = min(queued, HITQ);
-            for (uint32_t i = tid; i < nq; i += THREADS)
+            for (uint32_t i = tid; i < nq; i += THREADS) {
+                const uint2 h = hitq[i];
+                if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue; // two bases of one unit
                 verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, hitq[i].x,
-                            hitq[i].y, a.perm);
+                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, h.x, h.y, a.perm);
+            }
             __syncthreads();
             if (tid == 0) hitq_count = 0;
             flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, true);
