@@ -26,6 +26,29 @@ def test_hipnaive_remove_near_sequence_matches_naive():
         assert not d.contains("A" * L) or ("A" * L) in umis
 
 
+def test_hipnaive_on_a_wide_bucket():
+    """DataStruct path over a bucket large enough for the key-sorted table kernel: the
+    neighbour lists (with distances) come back in entry indices through the permutation."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(18)
+    L, k = 10, 2
+    raw = rng.integers(0, 4, (42000, L))
+    umis = sorted({"".join("ACGT"[c] for c in r) for r in raw})
+    rng.shuffle(umis)
+    freq = np.minimum(rng.geometric(0.5, len(umis)), 9).tolist()
+    assert len(umis) >= 32768
+    d = umi.HipNaive.new(dict(zip(umis, freq)), L, k)
+    o = orc.Naive(umis, freq)
+    for q in rng.permutation(len(umis))[:25]:
+        kk = int(rng.integers(0, k + 1))
+        mf = int(rng.integers(0, 6))
+        got = d.remove_near(umis[q], kk, mf)
+        exp = {umis[i] for i in o.remove_near(int(q), kk, mf)}
+        assert got == exp
+    probe = rng.permutation(len(umis))[:2000]
+    assert all(d.contains(umis[i]) == o.contains(int(i)) for i in probe)
+
+
 def test_algorithm_mirror_over_hipnaive(kat):
     import umi_collapse_rs_amd as umi
     g = kat["G8_bucket"]
