@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void k(const uint32_t *in, uint32_t *out, unsi
             for (int i = 0; i < 4; i++) {
                 uint32_t e0, e1, f0, f1;
                 const uint32_t i0 = key[i] & 15u, i1 = (key[i] >> 4) & 15u;
+                if (MODE == 8) {
+                    uint32_t ta, tb;
+                    asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "v_mov_b32 %1, v96\n\t"
+                                 "s_set_gpr_idx_idx %5\n\t"
+                                 "v_bitop3_b32 %2, v80, %6, %0 bitop3:0xe8\n\t"
+                                 "v_bitop3_b32 %3, v112, %7, %1 bitop3:0xe8\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e0), "=&v"(e1), "=&v"(ta), "=&v"(tb)
+                                 : "s"(i0), "s"(i1), "v"(anyP0), "v"(anyP1), "{v[64:79]}"(t00), "{v[80:95]}"(t01),
+                                   "{v[96:111]}"(t10), "{v[112:127]}"(t11));
+                    h[i][0] = BITOP3(twoP0, ta, valid, 0x02);
+                    h[i][1] = BITOP3(twoP1, tb, valid, 0x02);
+                    anyhit |= h[i][0] | h[i][1];
+                    continue;
+                }
                 if (MODE == 6) {
                     uint32_t g0, g1;
                     const uint32_t i2 = (key[i] >> 8) & 15u;
@@ -204,6 +221,7 @@ int main()
         run<3>("no index window", in, out, clk, w);
         run<4>("window only", in, out, clk, w);
         run<6>("three live units (6 tables), tree + merge", in, out, clk, w);
+        run<8>("second lookup folded into the majority op", in, out, clk, w);
         run_lds(in, out, clk, w);
     }
     return 0;

@@ -881,7 +881,12 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                 }
             }
         }
-        for (uint32_t cc = tid; cc < (uint32_t)TILE + 8; cc += THREADS) ckey[cc] = fkey[c0 + cc]; // (padded array)
+        for (uint32_t cc = tid; cc < (uint32_t)TILE + 8; cc += THREADS) { // (padded array)
+            // the two live unit values of the column, one per byte: s_set_gpr_idx_on / _idx take
+            // the low byte of their operand as the index, so no masking is left for the walk
+            const uint32_t kq = fkey[c0 + cc];
+            ckey[cc] = (kq & 15u) | (((kq >> 4) & 15u) << 8);
+        }
         for (uint32_t cc = tid; cc < (uint32_t)TILE; cc += THREADS) { // does column cc start a run of equal high bases?
             bool newrun = false;
             if (cc < nc) // the first column of the task, or high bases unlike the column before
@@ -938,40 +943,56 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
             // rows within the filter's reach of column c, whose (sorted) key is `key`
             auto eval_column = [&](uint32_t c, uint32_t key, uint32_t (&h)[G]) -> uint32_t {
                 uint32_t anyhit = 0;
-                uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u};
+                uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u}, maj2[2] = {0u, 0u};
                 if (LIVE == 2 && G == 2) {
                     // The four lookups of a column under one index-mode window: the compiler
                     // brackets every indexed move with its own s_set_gpr_idx_on/off, and the one
                     // scalar unit of a CU (one instruction per 4 cycles and SIMD) is what bounds
-                    // this loop.  The tables are pinned to v[64:127] for the statement.
-                    const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
-                    const uint32_t i0 = ukey & 15u, i1 = (ukey >> 4) & 15u;
-                    asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
-                        "v_mov_b32 %0, v64\n\t"
-                        "v_mov_b32 %1, v96\n\t"
-                        "s_set_gpr_idx_idx %5\n\t"
-                        "v_mov_b32 %2, v80\n\t"
-                        "v_mov_b32 %3, v112\n\t"
-                        "s_set_gpr_idx_off"
-                        : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(f2[0]), "=&v"(f2[1])
-                        : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t10),
-                          "{v[112:127]}"(t11));
+                    // this loop.  The tables are pinned to v[64:127] for the statement.  For
+                    // K = 1 the second pair of lookups is the indexed source of the majority op
+                    // itself (two moves fewer per column).
                     // (m0 is rewritten by the window; the compiler never keeps a value in m0
                     // across statements, and lists it as reserved, so it is not a clobber here)
+                    const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
+                    const uint32_t i0 = ukey, i1 = ukey >> 8; // ckey[] holds them one per byte
+                    if (K == 1) {
+                        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                                     "v_mov_b32 %0, v64\n\t"
+                                     "v_mov_b32 %1, v96\n\t"
+                                     "s_set_gpr_idx_idx %5\n\t"
+                                     "v_bitop3_b32 %2, v80, %6, %0 bitop3:0xe8\n\t"
+                                     "v_bitop3_b32 %3, v112, %7, %1 bitop3:0xe8\n\t"
+                                     "s_set_gpr_idx_off"
+                                     : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(maj2[0]), "=&v"(maj2[1])
+                                     : "s"(i0), "s"(i1), "v"(pre[0][0]), "v"(pre[G - 1][0]), "{v[64:79]}"(t00),
+                                       "{v[80:95]}"(t01), "{v[96:111]}"(t10), "{v[112:127]}"(t11));
+                    } else {
+                        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                                     "v_mov_b32 %0, v64\n\t"
+                                     "v_mov_b32 %1, v96\n\t"
+                                     "s_set_gpr_idx_idx %5\n\t"
+                                     "v_mov_b32 %2, v80\n\t"
+                                     "v_mov_b32 %3, v112\n\t"
+                                     "s_set_gpr_idx_off"
+                                     : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(f2[0]), "=&v"(f2[1])
+                                     : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t10),
+                                       "{v[112:127]}"(t11));
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     auto unit = [&](int u) {
                         if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
-                        return lookup(g, u, (key >> (4 * u)) & 15u);
+                        return lookup(g, u, (key >> (8 * u)) & 15u);
                     };
                     uint32_t hg;
                     if (K == 1) {
                         if (LIVE == 1) {
                             hg = BITOP3(pre[g][1], pre[g][0] & unit(0), valid[g], ~(TT_A | TT_B) & TT_C);
                         } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
-                            const uint32_t t = BITOP3(pre[g][0], unit(0), unit(1),
-                                                      (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                            const uint32_t t = G == 2 ? maj2[g]
+                                                      : BITOP3(pre[g][0], unit(0), unit(1),
+                                                               (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
                             hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
                         } else {
                             uint32_t any, two;
