@@ -1053,21 +1053,28 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                 const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
 #pragma unroll
                 for (int i = 0; i < NCOL; i++) next[i] = ckey[c + i];
-                while (c < e) {
+                for (; c + NCOL <= e; c += NCOL) { // whole groups: straight-line code
                     uint32_t key[NCOL], h[NCOL][G];
 #pragma unroll
                     for (int i = 0; i < NCOL; i++) key[i] = __builtin_amdgcn_readfirstlane(next[i]);
 #pragma unroll
                     for (int i = 0; i < NCOL; i++) next[i] = ckey[c + NCOL + i];
-                    const uint32_t cnt = e - c; // columns of this group that belong to the run
                     uint32_t anyhit = 0;
 #pragma unroll
-                    for (int i = 0; i < NCOL; i++) {
-                        const uint32_t hit = eval_column(c + i, key[i], h[i]);
-                        if (i == 0) {
-                            anyhit |= hit;
-                        } else if ((uint32_t)i < cnt) { // (wave-uniform)
-                            anyhit |= hit;
+                    for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i, key[i], h[i]);
+                    if (__any(anyhit != 0)) {
+#pragma unroll
+                        for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
+                    }
+                }
+                if (c < e) { // the run's last 1..NCOL-1 columns: one more hit test for them
+                    uint32_t h[NCOL][G];
+                    const uint32_t cnt = e - c;
+                    uint32_t anyhit = 0;
+#pragma unroll
+                    for (int i = 0; i < NCOL - 1; i++) {
+                        if ((uint32_t)i < cnt) { // (wave-uniform)
+                            anyhit |= eval_column(c + i, __builtin_amdgcn_readfirstlane(next[i]), h[i]);
                         } else {
 #pragma unroll
                             for (int g = 0; g < G; g++) h[i][g] = 0u;
@@ -1075,9 +1082,9 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                     }
                     if (__any(anyhit != 0)) {
 #pragma unroll
-                        for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
+                        for (int i = 0; i < NCOL - 1; i++) queue_hits(c + i, h[i]);
                     }
-                    c += min(cnt, (uint32_t)NCOL);
+                    c = e;
                 }
             }
         };
