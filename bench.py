@@ -26,8 +26,8 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_CONFIG2 = (377901.9 + 45912.2) * 1024  # bytes per bs_tab_kernel launch at config 2:
-# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v7.csv
+TRAFFIC_CONFIG2 = (303869.2 + 35640.6) * 1024  # bytes per bs_tab_kernel launch at config 2:
+# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v8.csv
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
 # and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
 # counter over the L'/unit units: 0.5 per unit for K = 0, K+1 per unit for K > 1, and for
@@ -67,11 +67,14 @@ def table_kernel_shape(n_max, umi_len, opts):
 
 
 def table_ops_per_pair(k, shape):
-    """Algorithmic lane-ops per pair of bs_tab_kernel: per column and 32-row group `live`
-    register-indexed moves and the merge (2 bitop3 for k = 1, (k+1) per live unit otherwise),
+    """Algorithmic lane-ops per pair of bs_tab_kernel: per column and 32-row group the
+    register-indexed lookups (1 move for k = 1, `live` otherwise) and the merge (2 bitop3 for
+    k = 1, (k+1) per live unit otherwise),
     plus the prefix state (4 mask ops per prefix unit and its counter ops) once per column run."""
     live, pu, run = shape
     merge = 2.0 if k == 1 else (0.5 * live if k == 0 else (k + 1.0) * live)
+    if k == 1:
+        live -= 1  # the second lookup is the indexed source of the majority op, not a move
     tree = {0: 0.5 * pu, 1: 2.0 * (pu // 3) + (pu % 3) + max(0, (pu + 2) // 3 - 1)}.get(k, (k + 1.0) * pu)
     return (live + merge + (4.0 * pu + tree) / max(run, 1.0)) / 32.0
 
@@ -320,8 +323,8 @@ def main():
                 "note": "integer VALU roofline (0 algorithmic HBM bytes per pair; no MFMA).  "
                         "achieved = ops_per_pair x W / time of the pair kernels of one step (HIP "
                         "events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The table kernel "
-                        "needs 5.7x fewer lane-ops per pair than the mask kernel it replaced "
-                        "(0.165 vs 0.94 at L=12, k=1) and is bound by per-wave instruction issue "
+                        "needs 7x fewer lane-ops per pair than the mask kernel it replaced "
+                        "(0.134 vs 0.94 at L=12, k=1) and is bound by per-wave instruction issue "
                         "and the scalar unit, not by VALU throughput: frac fell while pairs/s rose "
                         "(DESIGN.md section 7).  HBM view in roofline_hbm."},
             "roofline_hbm": {
