@@ -100,6 +100,35 @@ def test_config2_one_million_reads_single_position(ctx):
     assert st3["n_pairs_evaluated"] < stats["n_pairs_evaluated"] // 3
 
 
+@pytest.mark.parametrize("L,k,n_reads", [(13, 1, 1_300_000), (12, 2, 600_000), (11, 0, 500_000)])
+def test_table_kernel_against_the_other_tile_kernels(L, k, n_reads):
+    """Deep positions the oracle cannot walk in test time: the key-sorted table kernel (also its
+    16-base shape, which needs > 10^6 entries to be chosen), the key-sorted mask kernel and the
+    unsorted one must agree bit for bit, and the result must be a fixed point (P2)."""
+    import umi_collapse_rs_amd as umi
+    from umi_collapse_rs_amd import synth
+    st = synth.config2(seed=40 + L, n_reads=n_reads, umi_len=L)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    outs = []
+    for opts in ({}, {"bs_tables": 0}, {"bs_sorted": 0}):
+        c = umi.Context(0)
+        try:
+            for name, v in opts.items():
+                c.set_option(name, v)
+            outs.append(c.dedup_batch(keys, None, freq, off, L, k=k, percentage=0.5))
+        finally:
+            c.close()
+    kept, root, stats = outs[0]
+    check_structure(kept, root, off)
+    for kept_o, root_o, st_o in outs[1:]:
+        assert (kept_o == kept).all() and (root_o == root).all()
+        assert st_o["n_edges"] == stats["n_edges"]
+    if k > 0:
+        rng = np.random.default_rng(1)
+        sample = np.concatenate([rng.choice(len(keys), 100, replace=False), np.nonzero(kept == 0)[0][:50]])
+        check_fixed_point(keys, freq, root, off, k, 0.5, sample, rng)
+
+
 def test_config3_many_small_buckets(ctx):
     from umi_collapse_rs_amd import synth
     st = synth.config3(seed=3, n_reads=10_000_000, n_positions=100_000, umi_len=12)
