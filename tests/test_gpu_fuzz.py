@@ -63,3 +63,37 @@ def test_fuzz_against_oracle(seed):
             ctx.close()
         assert (kept == okept).all(), (seed, L, k, p, algo, amf, opts, np.nonzero(kept != okept)[0][:5])
         assert (root == oroot).all(), (seed, L, k, p, algo, amf, opts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_wide_buckets(seed):
+    """The same differential fuzz on buckets of 33k-50k entries (key-sorted table kernel, mask
+    kernel with cached prefix state, 64-bit keys), next to a few small buckets in one call."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(7000 + seed)
+    L = int(rng.choice([8, 9, 10, 11, 12, 13, 17, 20]))
+    k = int(rng.choice([0, 1, 1, 2, 3]))
+    p = float(rng.choice([0.5, 0.5, 0.3, 1.0]))
+    algo, amf = (0, 0) if rng.random() < 0.7 else (1, int(rng.choice([1, 3])))
+    n_frac = float(rng.choice([0.0, 0.0, 0.01]))
+    cap = 4 ** L // 2
+    sizes = [int(rng.integers(33_000, 50_000)), 70, 1, int(rng.integers(2_000, 5_000))]
+    rng.shuffle(sizes)
+    keys, nm, fr, off = [], [], [], [0]
+    for n_target in sizes:
+        umis, freq = clustered_bucket(rng, min(n_target, cap), L, n_frac)
+        kk, mm = orc.encode_keys(umis)
+        keys.append(kk); nm.append(mm); fr.extend(freq); off.append(off[-1] + len(umis))
+    keys, nm = np.concatenate(keys), np.concatenate(nm)
+    fr, off = np.array(fr, np.int32), np.array(off, np.uint64)
+    okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
+    for opts in ({}, {"bs_tables": 0}, {"prune": 1}):
+        ctx = umi.Context(0)
+        try:
+            for name, v in opts.items():
+                ctx.set_option(name, v)
+            kept, root, st = ctx.dedup_batch(keys, nm if nm.any() else None, fr, off, L, k, p, algo, amf)
+        finally:
+            ctx.close()
+        assert (kept == okept).all(), (seed, L, k, p, algo, amf, opts, np.nonzero(kept != okept)[0][:5])
+        assert (root == oroot).all(), (seed, L, k, p, algo, amf, opts)
