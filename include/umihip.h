@@ -70,7 +70,8 @@ void umi_ctx_destroy(umi_ctx *ctx);
 /* Thread-local text of the last failure on this thread ("" if none). */
 const char *umi_last_error(void);
 /* Options: "profile" (0/1: record HIP events, fill ms_*), "edge_capacity"
- * (initial edge-list capacity, entries), "small_max" (largest bucket handled by
+ * (initial edge-list capacity, entries), "ovf_capacity" (initial capacity of the list of filter
+ * hits that do not fit a block's on-chip queue; both lists grow by themselves), "small_max" (largest bucket handled by
  * the wave-per-chunk kernel), "bitslice" (0/1: use the bit-sliced tile kernel for
  * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
  * bit-sliced task), "fused_max" (largest bucket handled by the fused one-wave-per-bucket

@@ -320,6 +320,15 @@ def test_wide_sorted_bucket_dense_in_neighbours(L, k):
         assert st0["n_edges"] == st["n_edges"]
     finally:
         c.close()
+    # the global overflow list itself too short at first: everything again with a longer one
+    c = umi.Context(0)
+    c.set_option("ovf_capacity", 16)
+    c.set_option("edge_capacity", 64)
+    try:
+        st1 = check_against_oracle(c, keys, nm, fr, off, L, k)
+        assert st1["n_edges"] == st["n_edges"]
+    finally:
+        c.close()
 
 
 def test_edge_list_overflow_is_transparent():

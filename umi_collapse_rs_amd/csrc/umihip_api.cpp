@@ -117,6 +117,7 @@ struct umi_ctx {
     hipStream_t own_stream = nullptr;
     bool profile = false;
     uint64_t edge_capacity = 1u << 20;
+    uint64_t ovf_capacity = 1u << 18; // filter hits beyond the blocks' LDS queues (grows like the edge list)
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
@@ -127,7 +128,7 @@ struct umi_ctx {
     bool bs_tables = true; // ... and look the low units up in per-lane register tables (32-bit keys)
     bool two_phase = true; // directional collapse: components of the symmetric pairs, then the DAG
     // workspace
-    DevBuf fkey, thr, label, lab, edges, edge_dist, tasks, counters, changed, boff, status, blocked;
+    DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, tasks, counters, changed, boff, status, blocked;
     DevBuf bs_tasks, plane_tasks, planes, ranges;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
@@ -741,6 +742,8 @@ class Pipeline {
             if ((rc = ctx->edges.reserve(cap * sizeof(uint2)))) return rc;
             if (mode == MODE_NEIGHBOURS && (rc = ctx->edge_dist.reserve(cap))) return rc;
             cap_used = (uint32_t)cap;
+            uint64_t ovf_cap = std::min<uint64_t>(std::max<uint64_t>(ctx->ovf_capacity, 1024), 0x7FFFFFF0ull);
+            if ((rc = ctx->ovf.reserve(ovf_cap * sizeof(uint2)))) return rc;
             PairArgs a;
             a.keys = d_keys;
             a.nmask = d_nmask;
@@ -754,6 +757,8 @@ class Pipeline {
             a.edges = ctx->edges.as<uint2>();
             a.edge_dist = ctx->edge_dist.as<uint8_t>();
             a.counters = d_cnt;
+            a.ovf = ctx->ovf.as<uint2>();
+            a.ovf_cap = (uint32_t)ovf_cap;
             a.edge_cap = cap_used;
             a.k = k;
             a.mode = mode;
@@ -779,15 +784,30 @@ class Pipeline {
             HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
             for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
             st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
-            if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             if ((rc = sync_counters())) return rc;
+            // filter hits that did not fit the blocks' LDS queues (very dense tiles): checked now,
+            // or -- if their list ran over as well -- everything again with a longer list
+            const uint64_t n_ovf = ctx->h_counters[CNT_OVF];
+            bool redo = false;
+            if (n_ovf > ovf_cap) {
+                ctx->ovf_capacity = n_ovf + n_ovf / 8 + 1024;
+                redo = true;
+            } else if (n_ovf) {
+                HIP_TRY(launch_verify_list(b, key32, (uint32_t)n_ovf, s));
+                st.n_pair_launches += 1;
+                if ((rc = sync_counters())) return rc;
+            }
+            if (prof && !redo) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             n_edges = ctx->h_counters[CNT_EDGES];
             st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
-            if (n_edges <= cap) break;
-            if (attempt >= 2) return fail(UMI_ERR_HIP, "edge list overflow persists");
-            cap = n_edges + n_edges / 16 + 1024;
-            ctx->edge_capacity = cap;
+            if (!redo && n_edges <= cap) break;
+            if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
+            if (n_edges > cap) {
+                cap = n_edges + n_edges / 16 + 1024;
+                ctx->edge_capacity = cap;
+            }
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_OVF], 0, sizeof(unsigned long long), s));
         }
         st.n_edges = n_edges;
         return UMI_OK;
@@ -1014,7 +1034,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->ranges, &ctx->fkey_sorted, &ctx->perm,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
-                      &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,
+                      &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
@@ -1060,6 +1080,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->bs_col_chunk = (uint32_t)value;
     } else if (!strcmp(name, "bitslice")) {
         ctx->use_bitslice = value != 0;
+    } else if (!strcmp(name, "ovf_capacity")) {
+        if (value < 1) return fail(UMI_ERR_ARG, "ovf_capacity must be >= 1");
+        ctx->ovf_capacity = (uint64_t)value;
     } else if (!strcmp(name, "small_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "small_max must be >= 0");
         ctx->small_max = (uint32_t)std::min<int64_t>(value, 1 << 30);

@@ -32,6 +32,7 @@ enum Counter : int {
     CNT_UNKNOWN = 4,    // adjacency collapse: undecided entries
     CNT_RISES = 5,      // entries whose freq is above their predecessor's
     CNT_START_RISES = 6, // ... of which sit at the start of a bucket (the only legal place)
+    CNT_OVF = 7,        // filter hits that did not fit a block's LDS queue (global overflow list)
     CNT_COUNT = 8,
 };
 
@@ -79,6 +80,8 @@ struct PairArgs {
     uint2 *edges;
     uint8_t *edge_dist; // MODE_NEIGHBOURS only
     unsigned long long *counters;
+    uint2 *ovf;        // (row, column) of the filter hits beyond a block's LDS queue, tile indices
+    uint32_t ovf_cap;
     uint32_t edge_cap;
     int k;
     int mode;
@@ -118,6 +121,8 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int prefix_units, hipStream_t s);
 hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s);
+// exact check of the n_entries filter hits in a.ovf (the bit-sliced kernels' overflow list)
+hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries, hipStream_t s);
 
 // ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
 size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits);

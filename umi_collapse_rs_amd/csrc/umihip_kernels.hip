@@ -654,12 +654,13 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
                         hh &= hh - 1;
                         const uint32_t row = bucket_start + rbase[g] + j;
                         const unsigned int slot = atomicAdd(&hitq_count, 1u);
-                        if (slot < HITQ)
+                        if (slot < HITQ) {
                             hitq[slot] = make_uint2(row, c0 + c);
-                        else // queue full (a very dense tile): check it here and now
-                            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
-                                        &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
-                                        row, c0 + c, a.perm);
+                        } else { // queue full (a very dense tile): to the global overflow list,
+                                 // which verify_list_kernel works off after this launch
+                            const unsigned long long pos = atomicAdd(&a.counters[CNT_OVF], 1ull);
+                            if (pos < a.ovf_cap) a.ovf[pos] = make_uint2(row, c0 + c);
+                        }
                     }
                 }
             };
@@ -1026,12 +1027,13 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                         hh &= hh - 1;
                         const uint32_t row = bucket_start + rbase[g] + j;
                         const unsigned int slot = atomicAdd(&hitq_count, 1u);
-                        if (slot < HITQ)
+                        if (slot < HITQ) {
                             hitq[slot] = make_uint2(row, c0 + c);
-                        else // queue full (a very dense tile): check it here and now
-                            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters,
-                                        &stage, a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1,
-                                        row, c0 + c, a.perm);
+                        } else { // queue full (a very dense tile): to the global overflow list,
+                                 // which verify_list_kernel works off after this launch
+                            const unsigned long long pos = atomicAdd(&a.counters[CNT_OVF], 1ull);
+                            if (pos < a.ovf_cap) a.ovf[pos] = make_uint2(row, c0 + c);
+                        }
                     }
                 }
             };
@@ -1111,6 +1113,35 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
     }
     __syncthreads();
     if (tid == 0 && stage.candidates)
+        atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
+}
+
+// ---- the overflow list of the bit-sliced kernels ------------------------------------
+// Filter hits that found their block's LDS queue full: (row, column) in tile indices, one per
+// thread through the same base-level pre-check and exact check as the queued ones.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void verify_list_kernel(PairArgs a, uint32_t n_entries)
+{
+    __shared__ EdgeStage stage;
+    if (threadIdx.x == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+    }
+    __syncthreads();
+    const KeyT *__restrict__ fkey = (const KeyT *)a.fkey;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n_entries; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n_entries) {
+            const uint2 h = a.ovf[i];
+            if (filter_key_distance(fkey[h.x], fkey[h.y]) <= a.k)
+                verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                            a.edge_cap, a.k, a.mode, a.adj_max_freq, 0xFFFFFFFFu, 0xFFFFFFFFu, h.x, h.y,
+                            a.perm);
+        }
+        flush_edges<256>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, a.mode == MODE_NEIGHBOURS, true);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && stage.candidates)
         atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
 }
 
@@ -1932,6 +1963,14 @@ hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipSt
     if (lp == 8) launch_tab_lp<8>(a, n_tasks, s);
     else if (lp == 12) launch_tab_lp<12>(a, n_tasks, s);
     else launch_tab_lp<16>(a, n_tasks, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries, hipStream_t s)
+{
+    if (n_entries == 0) return hipSuccess;
+    if (key32) verify_list_kernel<uint32_t><<<grid_for(n_entries, 256, 1024), 256, 0, s>>>(a, n_entries);
+    else verify_list_kernel<uint64_t><<<grid_for(n_entries, 256, 1024), 256, 0, s>>>(a, n_entries);
     return hipGetLastError();
 }
 
