@@ -121,6 +121,8 @@ struct umi_ctx {
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
+    uint32_t bs_tab_chunk = BS_TAB_COL_CHUNK;
+    uint32_t bs_tab_sub = BS_TAB_SUB;
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
@@ -171,7 +173,7 @@ int range_distance_bound(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b
 
 // Tile tasks of the bit-sliced kernel for every large bucket.  samples (prune mode, else
 // null): per bucket the sorted filter keys at positions s, s+128, ..., and e-1.
-void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
+void gen_bs_tasks(Plan &pl, int umi_len, uint32_t mask_chunk, uint32_t tab_chunk, int k,
                   const std::vector<std::vector<uint64_t>> *samples, bool key32)
 {
     const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
@@ -179,7 +181,8 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
     for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
         const Plan::BsBucket &bb = pl.bs_buckets[bi];
         const uint64_t s = bb.s, e = bb.e;
-        const uint32_t tile_groups = bb.live ? 256u * (uint32_t)BS_TAB_G2 : (bb.wide ? 256u : 64u) * gpl;
+        const uint32_t tile_groups = bb.live ? 64u * (uint32_t)BS_TAB_G2 : (bb.wide ? 256u : 64u) * gpl;
+        const uint32_t col_chunk = bb.live ? tab_chunk : mask_chunk;
         const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
         std::vector<BsTask> &list = pl.bs_tasks[bb.live ? 4 : (!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1)))];
         auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
@@ -464,7 +467,7 @@ class Pipeline {
             // the sorts are enqueued first: the host cuts the tile tasks (tens of thousands for a
             // deep position) while they run
             if (need_pairs && pl.any_sorted() && (rc = sort_stage())) return rc;
-            gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
+            gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, ctx->bs_tab_chunk, k, nullptr, key32);
             for (auto &v : pl.bs_tasks) keep_my_share(v);
         }
         if ((rc = upload_bitsliced())) return rc;
@@ -652,7 +655,7 @@ class Pipeline {
             samples[bi].assign(flat.begin() + o, flat.begin() + o + cnt);
             o += cnt;
         }
-        gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
+        gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, ctx->bs_tab_chunk, k, &samples, key32);
         for (auto &v : pl.bs_tasks) keep_my_share(v);
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
@@ -773,7 +776,8 @@ class Pipeline {
                 PairArgs w = b;
                 w.bs_tasks = b.bs_tasks + first;
                 if (li == 4)
-                    HIP_TRY(launch_bs_tab(w, (uint32_t)pl.bs_tasks[li].size(), umi_len, s));
+                    HIP_TRY(launch_bs_tab(w, (uint32_t)pl.bs_tasks[li].size(), umi_len, ctx->bs_tab_chunk,
+                                          std::min(ctx->bs_tab_sub, ctx->bs_tab_chunk), s));
                 else
                     HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
                                             ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
@@ -1078,6 +1082,16 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
             return fail(UMI_ERR_ARG, "bs_col_chunk must be a multiple of %d in %d..%d", BS_COL_TILE,
                         BS_COL_TILE, 1 << 24);
         ctx->bs_col_chunk = (uint32_t)value;
+    } else if (!strcmp(name, "bs_tab_chunk")) {
+        if (value < BS_TAB_TILE || value > (1 << 24) || value % BS_TAB_TILE)
+            return fail(UMI_ERR_ARG, "bs_tab_chunk must be a multiple of %d in %d..%d", BS_TAB_TILE,
+                        BS_TAB_TILE, 1 << 24);
+        ctx->bs_tab_chunk = (uint32_t)value;
+    } else if (!strcmp(name, "bs_tab_sub")) {
+        if (value < BS_TAB_TILE || value > (1 << 24) || value % BS_TAB_TILE)
+            return fail(UMI_ERR_ARG, "bs_tab_sub must be a multiple of %d in %d..%d", BS_TAB_TILE,
+                        BS_TAB_TILE, 1 << 24);
+        ctx->bs_tab_sub = (uint32_t)value;
     } else if (!strcmp(name, "bitslice")) {
         ctx->use_bitslice = value != 0;
     } else if (!strcmp(name, "ovf_capacity")) {

@@ -56,6 +56,9 @@ struct RangeTask {
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
 constexpr int BS_TAB_G2 = 2;    // row groups per lane of the table variant with 2 live units
+constexpr int BS_TAB_TILE = 256;       // columns it stages per step (one wave per task)
+constexpr int BS_TAB_COL_CHUNK = 4096; // default columns per task (ctx option bs_tab_chunk)
+constexpr int BS_TAB_SUB = 512;        // ... and per block (ctx option bs_tab_sub)
 constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
 // One wave transposes 64 rows of one bucket into bit planes.
@@ -120,7 +123,9 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int prefix_units, hipStream_t s);
-hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s);
+// task_cols: columns per task of the list (at most); every task is run as blocks of sub_cols columns
+hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, uint32_t task_cols,
+                         uint32_t sub_cols, hipStream_t s);
 // exact check of the n_entries filter hits in a.ovf (the bit-sliced kernels' overflow list)
 hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries, hipStream_t s);
 

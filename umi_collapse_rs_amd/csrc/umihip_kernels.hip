@@ -761,132 +761,181 @@ __device__ __forceinline__ u32x16 unit_table(const uint4 &q, std::integer_sequen
 }
 
 template <int LP, int K, int LIVE, int G>
-__global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
+__global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, uint32_t subs_per_task, uint32_t sub_cols)
 {
-    constexpr int THREADS = 256;
+    constexpr int THREADS = 64;    // one wave per block: no wave waits for another one's columns
     constexpr int NP = 2 * LP;
     constexpr int U = LP / 2;      // 2-base units per key
-    constexpr int PU = U - LIVE;   // prefix units: masks from LDS, state cached per column run
-    constexpr int PW = 4 * PU;     // prefix mask words per column
-    constexpr int TILE = BS_COL_TILE; // columns staged per barrier pair
+    constexpr int PU = U - LIVE;   // prefix units: state cached per column run
+    constexpr int PA = PU - 1;     // ... of which the coarse early out looks at all but the lowest
+    constexpr int PW = 4 * PU;     // prefix planes per row group
+    constexpr int TILE = BS_TAB_TILE; // columns staged per step
     static_assert(LIVE >= 1 && LIVE <= 4 && PU >= 1, "table variant: 1..4 live units and a prefix");
     static_assert(LIVE == 2 && G == 2, "only the tuned shape is instantiated (launch_bs_tab)");
-    __shared__ __attribute__((aligned(16))) uint32_t pmask[TILE * PW];
+    static_assert(4 * PU <= 32, "prefix bits of a column in one word");
     __shared__ uint32_t runbits[TILE / 32];
-    __shared__ uint32_t ckey[TILE + 8]; // the tile's column keys (+ the group read ahead past its end)
+    __shared__ uint32_t ckey[TILE + 8]; // live unit values of the tile's columns (+ the group read ahead past its end)
+    __shared__ uint32_t pkey[TILE];     // their prefix bits (unit q of the prefix = bits 4q .. 4q+3)
     __shared__ uint32_t nxt[TILE];      // first column after c that starts a run (or the tile's end)
-    constexpr uint32_t HITQ = 1024;
+    constexpr uint32_t HITQ = 256;
     __shared__ uint2 hitq[HITQ];
     __shared__ unsigned int hitq_count;
     __shared__ EdgeStage stage;
-    const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x;
+    // A task of the host's list is cut into subs_per_task column ranges of sub_cols, one block
+    // each: the walked share of a task varies between none and all of it, and short blocks
+    // even that out without a longer task list.
+    const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x / subs_per_task;
     const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(tp->bucket_start);
     const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(tp->bucket_end);
     const uint32_t group0 = __builtin_amdgcn_readfirstlane(tp->group0);
     const uint32_t ngroups = __builtin_amdgcn_readfirstlane(tp->ngroups);
-    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0);
-    const uint32_t col1 = __builtin_amdgcn_readfirstlane(tp->col1);
-    const bool diag = __builtin_amdgcn_readfirstlane(tp->diag) != 0; // wave-uniform
+    const uint32_t task_col1 = __builtin_amdgcn_readfirstlane(tp->col1);
+    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0) + (blockIdx.x % subs_per_task) * sub_cols;
+    if (col0 >= task_col1) return;
+    const uint32_t col1 = min(task_col1, col0 + sub_cols);
     const uint32_t *__restrict__ fkey = (const uint32_t *)a.fkey;
     const uint32_t *__restrict__ planes = a.planes + tp->plane_off;
     const int tid = threadIdx.x;
     const bool with_dist = a.mode == MODE_NEIGHBOURS;
     const uint32_t n_rows = bucket_end - bucket_start;
+    // some column index <= some row index: needs the row < column mask (wave-uniform)
+    const bool diag = col0 < bucket_start + (group0 + 64u * G) * 32u;
+    constexpr bool EARLY = true;
+
+    uint32_t rbase[G], valid[G]; // bucket-relative index of the group's first row; its rows in range
+    uint32_t pp[G][PW];          // planes of the prefix units (plane j of the prefix = bit j of a column's pkey)
+    uint32_t grp[G];
+    auto load_quad = [&](int g, int q) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (grp[g] < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp[g] * NP + 4 * q);
+        return v;
+    };
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        grp[g] = group0 + (uint32_t)g * THREADS + (uint32_t)tid; // the wave's 64 * G groups are adjacent
+        rbase[g] = grp[g] * 32;
+        valid[g] = rbase[g] >= n_rows ? 0u
+                   : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
+#pragma unroll
+        for (int q = 0; q < PU; q++) {
+            const uint4 v = load_quad(g, LIVE + q);
+            pp[g][4 * q] = v.x;
+            pp[g][4 * q + 1] = v.y;
+            pp[g][4 * q + 2] = v.z;
+            pp[g][4 * q + 3] = v.w;
+        }
+    }
+    // rows of group g whose prefix unit u differs from that unit of the (wave-uniform) prefix
+    // bits pk: the column's bits become 0 / ~0 masks on the scalar side
+    auto prefix_unit = [&](int g, int u, uint32_t pk) {
+        uint32_t m = pp[g][4 * u] ^ (0u - ((pk >> (4 * u)) & 1u));
+#pragma unroll
+        for (int b = 1; b < 4; b++)
+            m = BITOP3(m, pp[g][4 * u + b], 0u - ((pk >> (4 * u + b)) & 1u), TT_A | (TT_B ^ TT_C));
+        return m;
+    };
+
+    // ---- coarse early out, before anything else is set up -------------------------------
+    // The bucket is sorted by key, so the columns of a tile share their highest bases.  A tile
+    // whose first and last column agree in the PA highest units (or are a few values of them
+    // apart: every value in between is tried) is walked only if those units leave some row of the wave within k:
+    // mismatches are sticky, so no column of the tile can hit otherwise.  Every pair is still
+    // decided by its own bits -- the high ones, which suffice.
+    const uint32_t ntiles = (col1 - col0 + TILE - 1) / TILE;
+    uint32_t alive_tiles = 0xFFFFFFFFu; // bit t: tile t must be walked (tiles past 32: always)
+    if (EARLY && PA > K) {
+        uint32_t kb = 0; // lane 2t: first key of tile t, lane 2t+1: its last key
+        {
+            const uint32_t t = (uint32_t)tid >> 1, c = col0 + t * TILE;
+            if (t < ntiles && c < col1) kb = fkey[(tid & 1) ? min(c + TILE, col1) - 1u : c];
+        }
+        uint32_t seen_p = 0xFFFFFFFFu;
+        bool seen_alive = true;
+        auto prefix_alive = [&](uint32_t p) { // p = prefix bits without the lowest prefix unit
+            if (p != seen_p) {
+                uint32_t open_rows = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    auto unit = [&](int u) { return prefix_unit(g, u, p << 4); }; // u = 1 .. PU-1
+                    if (K == 1) {
+                        uint32_t any = 0, two = 0;
+                        any_two_of_units<1, PU>(unit, any, two);
+                        open_rows |= ~two & valid[g];
+                    } else {
+                        uint32_t sc[K + 2];
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) sc[l] = 0;
+                        count_units<K, 1, PU>(unit, sc);
+                        open_rows |= ~sc[K + 1] & valid[g];
+                    }
+                }
+                seen_alive = __any(open_rows != 0);
+                seen_p = p;
+            }
+            return seen_alive;
+        };
+        alive_tiles = 0;
+        const uint32_t nscan = min(ntiles, 32u);
+        for (uint32_t t = 0; t < nscan; t++) {
+            const uint32_t pf = __builtin_amdgcn_readlane(kb, 2 * t) >> (4 * (LIVE + 1));
+            const uint32_t pl = __builtin_amdgcn_readlane(kb, 2 * t + 1) >> (4 * (LIVE + 1));
+            bool alive = pl - pf > 3u; // (keys are sorted: pl >= pf; that many values in between: walk)
+            for (uint32_t p = pf; !alive && p <= pl; p++) alive = prefix_alive(p);
+            alive_tiles |= (alive ? 1u : 0u) << t;
+        }
+        if (ntiles <= 32 && alive_tiles == 0) return; // nothing of this task can hit
+    }
 
     if (tid == 0) {
         stage.count = 0;
         stage.candidates = 0;
         hitq_count = 0;
     }
-
-    uint32_t rbase[G], valid[G]; // bucket-relative index of the group's first row; its rows in range
-    uint32_t pp[G][PW];          // planes of the prefix units (quads: word j = plane 4q + j)
-    // tXY[v] = rows of group X whose live unit Y differs from value v.  Eight named vectors, not
+    // tXY[v] = rows of group X whose live unit Y differs from value v.  Four named vectors, not
     // an array: an array of vectors this large stays in scratch memory instead of registers.
-    u32x16 t00 = {}, t01 = {}, t02 = {}, t03 = {}, t10 = {}, t11 = {}, t12 = {}, t13 = {};
-    static_assert(G <= 2, "two table sets");
-    auto set_table = [&](int g, int u, const u32x16 &t) {
-        switch (g * 4 + u) {
-        case 0: t00 = t; break;
-        case 1: t01 = t; break;
-        case 2: t02 = t; break;
-        case 3: t03 = t; break;
-        case 4: t10 = t; break;
-        case 5: t11 = t; break;
-        case 6: t12 = t; break;
-        default: t13 = t; break;
-        }
-    };
-    auto lookup = [&](int g, int u, uint32_t v) -> uint32_t { // g, u: constants once unrolled
-        switch (g * 4 + u) {
-        case 0: return t00[v];
-        case 1: return t01[v];
-        case 2: return t02[v];
-        case 3: return t03[v];
-        case 4: return t10[v];
-        case 5: return t11[v];
-        case 6: return t12[v];
-        default: return t13[v];
-        }
-    };
+    u32x16 t00, t01, t10, t11;
+    t00 = unit_table(load_quad(0, 0), std::make_integer_sequence<int, 16>{});
+    t01 = unit_table(load_quad(0, 1), std::make_integer_sequence<int, 16>{});
+    t10 = unit_table(load_quad(1, 0), std::make_integer_sequence<int, 16>{});
+    t11 = unit_table(load_quad(1, 1), std::make_integer_sequence<int, 16>{});
     uint32_t pre[G][K + 2];      // counter state after the prefix units ((any, two) for K = 1)
+    bool dead = false;           // ... puts every row of the wave beyond k (wave-uniform)
+    bool stale = true;           // pre[] is not the state of the column before the tile's first
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const uint32_t grp = group0 + g * THREADS + tid;
-        rbase[g] = grp * 32;
-        valid[g] = rbase[g] >= n_rows ? 0u
-                   : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
-        auto load_quad = [&](int q) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (grp < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp * NP + 4 * q);
-            return v;
-        };
-#pragma unroll
-        for (int u = 0; u < LIVE; u++)
-            set_table(g, u, unit_table(load_quad(u), std::make_integer_sequence<int, 16>{}));
-#pragma unroll
-        for (int q = 0; q < PU; q++) {
-            const uint4 v = load_quad(LIVE + q);
-            pp[g][4 * q] = v.x;
-            pp[g][4 * q + 1] = v.y;
-            pp[g][4 * q + 2] = v.z;
-            pp[g][4 * q + 3] = v.w;
-        }
+    for (int g = 0; g < G; g++)
 #pragma unroll
         for (int l = 0; l < K + 2; l++) pre[g][l] = 0u;
-    }
 
-    for (uint32_t c0 = col0; c0 < col1; c0 += TILE) {
-        const uint32_t nc = min((uint32_t)TILE, col1 - c0);
+    // Exact check of the queued filter hits, one per lane: a base-level test on the two filter
+    // keys first (the unit-level filter lets pairs through that differ in two bases of one
+    // unit), then the reference arithmetic.  The block is one wave, so the queue can be worked
+    // off wherever the wave stands -- when it is half full, or the task ends.
+    auto drain = [&](bool final) {
         __syncthreads();
-        { // stage the prefix masks: thread -> (column, quad); word j of a quad = plane 4q + (j ^ 1)
-            constexpr int ITEMS = (TILE * PU + THREADS - 1) / THREADS;
-            uint32_t ck[ITEMS];
-#pragma unroll
-            for (int it = 0; it < ITEMS; it++) {
-                const uint32_t c = ((uint32_t)tid + (uint32_t)it * THREADS) / PU;
-                ck[it] = c < nc ? fkey[c0 + c] : 0u;
-            }
-#pragma unroll
-            for (int it = 0; it < ITEMS; it++) {
-                const uint32_t w = (uint32_t)tid + (uint32_t)it * THREADS;
-                const uint32_t c = w / PU, q = w % PU;
-                if (c < nc) {
-                    const uint32_t bits = ck[it] >> (4 * (LIVE + q));
-                    uint4 v;
-                    v.x = (bits & 2u) ? 0xFFFFFFFFu : 0u;
-                    v.y = (bits & 1u) ? 0xFFFFFFFFu : 0u;
-                    v.z = (bits & 8u) ? 0xFFFFFFFFu : 0u;
-                    v.w = (bits & 4u) ? 0xFFFFFFFFu : 0u;
-                    *reinterpret_cast<uint4 *>(&pmask[c * PW + 4 * q]) = v;
-                }
-            }
+        const uint32_t nq = min(hitq_count, HITQ);
+        for (uint32_t i = tid; i < nq; i += THREADS) {
+            const uint2 h = hitq[i];
+            if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue;
+            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, h.x, h.y, a.perm);
         }
+        __syncthreads();
+        if (tid == 0) hitq_count = 0;
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, final);
+    };
+
+    uint32_t tile_no = 0;
+    for (uint32_t c0 = col0; c0 < col1; c0 += TILE, tile_no++) {
+        const uint32_t nc = min((uint32_t)TILE, col1 - c0);
+        const bool walk = tile_no >= 32 || ((alive_tiles >> tile_no) & 1u) != 0;
+        if (walk) {
+        __syncthreads();
         for (uint32_t cc = tid; cc < (uint32_t)TILE + 8; cc += THREADS) { // (padded array)
             // the two live unit values of the column, one per byte: s_set_gpr_idx_on / _idx take
             // the low byte of their operand as the index, so no masking is left for the walk
-            const uint32_t kq = fkey[c0 + cc];
+            const uint32_t kq = fkey[min(c0 + cc, bucket_end - 1u)]; // (columns past the end: never used)
             ckey[cc] = (kq & 15u) | (((kq >> 4) & 15u) << 8);
+            if (cc < (uint32_t)TILE) pkey[cc] = kq >> (4 * LIVE);
         }
         for (uint32_t cc = tid; cc < (uint32_t)TILE; cc += THREADS) { // does column cc start a run of equal high bases?
             bool newrun = false;
@@ -916,19 +965,10 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
             constexpr bool DIAG = decltype(diag_tag)::value;
             constexpr int NCOL = 4; // columns per "any hit?" test
             auto update_prefix = [&](uint32_t c) {
-                uint32_t cm[PW];
-#pragma unroll
-                for (int q = 0; q < PU; q++)
-                    *reinterpret_cast<uint4 *>(&cm[4 * q]) = *reinterpret_cast<const uint4 *>(&pmask[c * PW + 4 * q]);
+                const uint32_t pk = __builtin_amdgcn_readfirstlane(pkey[c]);
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    auto unit = [&](int u) { // u = 0 .. PU-1 over the prefix units
-                        uint32_t m = BITOP3(pp[g][4 * u], cm[(4 * u) ^ 1], cm[(4 * u) ^ 1], TT_A ^ TT_B);
-#pragma unroll
-                        for (int b = 1; b < 4; b++)
-                            m = BITOP3(m, pp[g][4 * u + b], cm[(4 * u + b) ^ 1], TT_A | (TT_B ^ TT_C));
-                        return m;
-                    };
+                    auto unit = [&](int u) { return prefix_unit(g, u, pk); }; // u = 0 .. PU-1
                     if (K == 1) {
                         any_two_of_units<0, PU>(unit, pre[g][0], pre[g][1]);
                     } else {
@@ -984,7 +1024,7 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                 for (int g = 0; g < G; g++) {
                     auto unit = [&](int u) {
                         if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
-                        return lookup(g, u, (key >> (8 * u)) & 15u);
+                        return 0u; // (other shapes: not instantiated)
                     };
                     uint32_t hg;
                     if (K == 1) {
@@ -1046,13 +1086,26 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
             // keys does not drain the reads issued after them; scalar loads from the key array
             // itself would, and they miss the scalar cache every 16 columns).
             uint32_t next[NCOL];
-            bool starts = (__builtin_amdgcn_readfirstlane(runbits[0]) & 1u) != 0; // is column 0 a run start?
+            // is column 0 a run start?  (also after tiles this wave did not walk)
+            bool starts = stale || (__builtin_amdgcn_readfirstlane(runbits[0]) & 1u) != 0;
             uint32_t c = 0;
             while (c < nc) {
                 c = __builtin_amdgcn_readfirstlane(c); // (uniform already; keeps it in an SGPR)
-                if (starts) update_prefix(c);
+                if (starts) {
+                    update_prefix(c);
+                    // early out: when the high units alone put every row of the wave beyond k, the
+                    // run's columns cannot hit (the state is sticky) -- skip their low units
+                    uint32_t open_rows = 0;
+#pragma unroll
+                    for (int g = 0; g < G; g++) open_rows |= ~pre[g][K == 1 ? 1 : K + 1] & valid[g];
+                    dead = EARLY && !__any(open_rows != 0);
+                }
                 starts = true; // every later run of the tile begins at a flagged column
                 const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
+                if (dead) {
+                    c = e;
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < NCOL; i++) next[i] = ckey[c + i];
                 for (; c + NCOL <= e; c += NCOL) { // whole groups: straight-line code
@@ -1067,6 +1120,8 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                     if (__any(anyhit != 0)) {
 #pragma unroll
                         for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
+                            drain(false);
                     }
                 }
                 if (c < e) { // the run's last 1..NCOL-1 columns: one more hit test for them
@@ -1085,6 +1140,8 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
                     if (__any(anyhit != 0)) {
 #pragma unroll
                         for (int i = 0; i < NCOL - 1; i++) queue_hits(c + i, h[i]);
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
+                            drain(false);
                     }
                     c = e;
                 }
@@ -1092,25 +1149,13 @@ __global__ __launch_bounds__(256, 3) void bs_tab_kernel(PairArgs a)
         };
         if (diag) walk_columns(std::true_type{});
         else walk_columns(std::false_type{});
-
-        // The queued hits are checked when the queue is half full or the task ends, not after
-        // every tile: the check is a chain of dependent global gathers (permutation, keys, freq,
-        // thresholds) that all four waves of the block would sit out 16 times per task.
-        __syncthreads();
-        const uint32_t queued = hitq_count; // the same for every thread: stable between the barriers
-        if (queued >= HITQ / 2 || c0 + TILE >= col1) {
-            const uint32_t nq = min(queued, HITQ);
-            for (uint32_t i = tid; i < nq; i += THREADS) {
-                const uint2 h = hitq[i];
-                if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue; // two bases of one unit
-                verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                            a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, h.x, h.y, a.perm);
-            }
-            __syncthreads();
-            if (tid == 0) hitq_count = 0;
-            flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, true);
+        stale = false;
+        } else {
+            stale = true;
         }
+
     }
+    drain(true);
     __syncthreads();
     if (tid == 0 && stage.candidates)
         atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
@@ -1938,31 +1983,34 @@ void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int 
 
 namespace {
 template <int LP, int K>
-void launch_tab_k(const PairArgs &a, uint32_t n_tasks, hipStream_t s)
+void launch_tab_k(const PairArgs &a, uint32_t n_tasks, uint32_t subs, uint32_t sub_cols, hipStream_t s)
 {
     // two live units looked up in the tables, the other LP/2 - 2 cached per column run
-    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_tasks, 256, 0, s>>>(a);
+    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_tasks * subs, 64, 0, s>>>(a, subs, sub_cols); // one wave per block
 }
 template <int LP>
-void launch_tab_lp(const PairArgs &a, uint32_t n_tasks, hipStream_t s)
+void launch_tab_lp(const PairArgs &a, uint32_t n_tasks, uint32_t subs, uint32_t sub_cols, hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_tab_k<LP, 0>(a, n_tasks, s); break;
-    case 1: launch_tab_k<LP, 1>(a, n_tasks, s); break;
-    case 2: launch_tab_k<LP, 2>(a, n_tasks, s); break;
-    default: launch_tab_k<LP, 3>(a, n_tasks, s); break;
+    case 0: launch_tab_k<LP, 0>(a, n_tasks, subs, sub_cols, s); break;
+    case 1: launch_tab_k<LP, 1>(a, n_tasks, subs, sub_cols, s); break;
+    case 2: launch_tab_k<LP, 2>(a, n_tasks, subs, sub_cols, s); break;
+    default: launch_tab_k<LP, 3>(a, n_tasks, subs, sub_cols, s); break;
     }
 }
 } // namespace
 
 // table variant: 32-bit keys, key-sorted buckets, BS_TAB_G2 row groups per lane, 2 live units
-hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, hipStream_t s)
+hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, uint32_t task_cols,
+                         uint32_t sub_cols, hipStream_t s)
 {
     if (n_tasks == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
-    if (lp == 8) launch_tab_lp<8>(a, n_tasks, s);
-    else if (lp == 12) launch_tab_lp<12>(a, n_tasks, s);
-    else launch_tab_lp<16>(a, n_tasks, s);
+    const uint32_t subs = (task_cols + sub_cols - 1) / sub_cols;
+    if ((uint64_t)n_tasks * subs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (lp == 8) launch_tab_lp<8>(a, n_tasks, subs, sub_cols, s);
+    else if (lp == 12) launch_tab_lp<12>(a, n_tasks, subs, sub_cols, s);
+    else launch_tab_lp<16>(a, n_tasks, subs, sub_cols, s);
     return hipGetLastError();
 }
 
