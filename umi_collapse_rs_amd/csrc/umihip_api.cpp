@@ -74,9 +74,13 @@ struct DevBuf {
 struct Plan {
     std::vector<PairTask> small_tasks, big_tasks;
     // bit-sliced tasks: [0] column-split tiles, [1] wide tiles, [2]/[3] wide tiles of key-sorted
-    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run,
-    // [4] table-variant tiles (key-sorted, 32-bit keys, 2 live units)
-    std::vector<BsTask> bs_tasks[5];
+    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run
+    std::vector<BsTask> bs_tasks[4];
+    // table variant (key-sorted, 32-bit keys, 2 live units): row tiles; the column tiles to walk
+    // are found on the device (tab_items_max = all of them)
+    std::vector<TabRowTile> tab_rows;
+    uint64_t tab_items_max = 0;
+    uint64_t n_pairs_eval_tab = 0; // their share of n_pairs_eval if every column tile were walked
     std::vector<PlaneTask> plane_tasks;
     // entries of the buckets the fused kernel does not take, in chunks: what prep and finalize
     // work on (empty for a batch of small positions)
@@ -121,8 +125,7 @@ struct umi_ctx {
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
-    uint32_t bs_tab_chunk = BS_TAB_COL_CHUNK;
-    uint32_t bs_tab_sub = BS_TAB_SUB;
+    uint32_t bs_tab_waves = 0; // persistent waves of the table kernel (0: 12 per CU)
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
@@ -131,7 +134,8 @@ struct umi_ctx {
     bool two_phase = true; // directional collapse: components of the symmetric pairs, then the DAG
     // workspace
     DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, tasks, counters, changed, boff, status, blocked;
-    DevBuf bs_tasks, plane_tasks, planes, ranges;
+    DevBuf bs_tasks, plane_tasks, planes, ranges, tab_rows, tab_items;
+    int n_cus = 256;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
     Plan plan;
@@ -173,7 +177,7 @@ int range_distance_bound(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b
 
 // Tile tasks of the bit-sliced kernel for every large bucket.  samples (prune mode, else
 // null): per bucket the sorted filter keys at positions s, s+128, ..., and e-1.
-void gen_bs_tasks(Plan &pl, int umi_len, uint32_t mask_chunk, uint32_t tab_chunk, int k,
+void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
                   const std::vector<std::vector<uint64_t>> *samples, bool key32)
 {
     const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
@@ -181,10 +185,20 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t mask_chunk, uint32_t tab_chunk
     for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
         const Plan::BsBucket &bb = pl.bs_buckets[bi];
         const uint64_t s = bb.s, e = bb.e;
-        const uint32_t tile_groups = bb.live ? 64u * (uint32_t)BS_TAB_G2 : (bb.wide ? 256u : 64u) * gpl;
-        const uint32_t col_chunk = bb.live ? tab_chunk : mask_chunk;
+        if (bb.live) { // table variant: one record per row tile
+            const uint32_t tile_groups = 64u * (uint32_t)BS_TAB_G2;
+            for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
+                const uint64_t r_lo = s + (uint64_t)g0 * 32;
+                pl.tab_rows.push_back(TabRowTile{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off});
+                pl.tab_items_max += (e - r_lo + BS_TAB_TILE - 1) / BS_TAB_TILE;
+                pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (e - r_lo);
+                pl.n_pairs_eval_tab += (uint64_t)tile_groups * 32 * (e - r_lo);
+            }
+            continue;
+        }
+        const uint32_t tile_groups = (bb.wide ? 256u : 64u) * gpl;
         const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
-        std::vector<BsTask> &list = pl.bs_tasks[bb.live ? 4 : (!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1)))];
+        std::vector<BsTask> &list = pl.bs_tasks[!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1))];
         auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
         auto key_hi = [&](uint64_t end) { // an upper bound of the last key of [.., end)
             if (end >= e) return smp->back();
@@ -259,6 +273,9 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
     pl.small_tasks.clear();
     pl.big_tasks.clear();
     for (auto &v : pl.bs_tasks) v.clear();
+    pl.tab_rows.clear();
+    pl.tab_items_max = 0;
+    pl.n_pairs_eval_tab = 0;
     pl.plane_tasks.clear();
     pl.bs_buckets.clear();
     pl.plane_words = 0;
@@ -467,7 +484,7 @@ class Pipeline {
             // the sorts are enqueued first: the host cuts the tile tasks (tens of thousands for a
             // deep position) while they run
             if (need_pairs && pl.any_sorted() && (rc = sort_stage())) return rc;
-            gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, ctx->bs_tab_chunk, k, nullptr, key32);
+            gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
             for (auto &v : pl.bs_tasks) keep_my_share(v);
         }
         if ((rc = upload_bitsliced())) return rc;
@@ -655,7 +672,7 @@ class Pipeline {
             samples[bi].assign(flat.begin() + o, flat.begin() + o + cnt);
             o += cnt;
         }
-        gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, ctx->bs_tab_chunk, k, &samples, key32);
+        gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, &samples, key32);
         for (auto &v : pl.bs_tasks) keep_my_share(v);
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
@@ -696,20 +713,26 @@ class Pipeline {
     // bit-sliced tile tasks + bit planes of the large buckets
     int upload_bitsliced()
     {
-        n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs();
+        n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + pl.tab_rows.size();
         if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
-        if (need_pairs && pl.n_bs()) {
+        if (need_pairs && (pl.n_bs() || !pl.tab_rows.empty())) {
             int rc;
-            if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask)))) return rc;
-            // through a pinned buffer (a megabyte of tasks at config 2: the runtime's staged copy
-            // of pageable memory runs at a fifth of the DMA rate and holds the stream meanwhile)
+            if (pl.tab_items_max > 0x7FFFFFF0ull / sizeof(TabItem))
+                return fail(UMI_ERR_NOMEM, "item list of the table kernel too large (set bs_tables=0)");
+            if ((rc = ctx->bs_tasks.reserve(pl.n_bs() * sizeof(BsTask))) ||
+                (rc = ctx->tab_rows.reserve(pl.tab_rows.size() * sizeof(TabRowTile))) ||
+                (rc = ctx->tab_items.reserve(pl.tab_items_max * sizeof(TabItem))))
+                return rc;
+            // through a pinned buffer (the runtime's staged copy of pageable memory runs at a
+            // fifth of the DMA rate and holds the stream meanwhile)
             const size_t bs_bytes = pl.n_bs() * sizeof(BsTask);
             const size_t plane_bytes = pl.plane_tasks.size() * sizeof(PlaneTask);
-            if (ctx->h_tasks_cap < bs_bytes + plane_bytes) {
+            const size_t row_bytes = pl.tab_rows.size() * sizeof(TabRowTile);
+            if (ctx->h_tasks_cap < bs_bytes + plane_bytes + row_bytes) {
                 if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
                 ctx->h_tasks = nullptr;
                 ctx->h_tasks_cap = 0;
-                const size_t want = (bs_bytes + plane_bytes) * 5 / 4 + 4096;
+                const size_t want = (bs_bytes + plane_bytes + row_bytes) * 5 / 4 + 4096;
                 HIP_TRY(hipHostMalloc(&ctx->h_tasks, want));
                 ctx->h_tasks_cap = want;
             }
@@ -719,8 +742,12 @@ class Pipeline {
                 memcpy(h + off, v.data(), v.size() * sizeof(BsTask));
                 off += v.size() * sizeof(BsTask);
             }
+            if (row_bytes) {
+                memcpy(h + bs_bytes + plane_bytes, pl.tab_rows.data(), row_bytes);
+                HIP_TRY(hipMemcpyAsync(ctx->tab_rows.p, h + bs_bytes + plane_bytes, row_bytes, hipMemcpyHostToDevice, s));
+            }
             memcpy(h + bs_bytes, pl.plane_tasks.data(), plane_bytes);
-            HIP_TRY(hipMemcpyAsync(ctx->bs_tasks.p, h, bs_bytes, hipMemcpyHostToDevice, s));
+            if (bs_bytes) HIP_TRY(hipMemcpyAsync(ctx->bs_tasks.p, h, bs_bytes, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, h + bs_bytes, plane_bytes, hipMemcpyHostToDevice, s));
             HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
                                         (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
@@ -770,23 +797,24 @@ class Pipeline {
             PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
             b.fkey = bs_fkey;
             b.perm = bs_perm;
+            if (!pl.tab_rows.empty()) // the table variant first (the largest buckets)
+                HIP_TRY(launch_bs_tab(b, ctx->tab_rows.as<TabRowTile>(), (uint32_t)pl.tab_rows.size(),
+                                      ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
+                                      n_parts, ctx->bs_tab_waves ? ctx->bs_tab_waves : 12u * (uint32_t)ctx->n_cus, s));
             size_t first = pl.n_bs();
-            for (int li = 4; li >= 0; li--) { // lists sit in the device array in index order
+            for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
                 first -= pl.bs_tasks[li].size();
                 PairArgs w = b;
                 w.bs_tasks = b.bs_tasks + first;
-                if (li == 4)
-                    HIP_TRY(launch_bs_tab(w, (uint32_t)pl.bs_tasks[li].size(), umi_len, ctx->bs_tab_chunk,
-                                          std::min(ctx->bs_tab_sub, ctx->bs_tab_chunk), s));
-                else
-                    HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
-                                            ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
+                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
+                                        ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
             }
             PairArgs big = a;
             big.tasks = a.tasks + pl.small_tasks.size();
             HIP_TRY(launch_pairs(big, (uint32_t)pl.big_tasks.size(), true, key32, s));
             HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
             for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
+            st.n_pair_launches += pl.tab_rows.empty() ? 0 : 2;
             st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
             if ((rc = sync_counters())) return rc;
             // filter hits that did not fit the blocks' LDS queues (very dense tiles): checked now,
@@ -804,6 +832,10 @@ class Pipeline {
             if (prof && !redo) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             n_edges = ctx->h_counters[CNT_EDGES];
             st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
+            if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
+                st.n_pairs_evaluated = pl.n_pairs_eval - pl.n_pairs_eval_tab +
+                                       (ctx->h_counters[CNT_ITEMS] + ctx->h_counters[CNT_DIAG_ITEMS]) *
+                                           (64ull * BS_TAB_G2 * 32) * BS_TAB_TILE;
             if (!redo && n_edges <= cap) break;
             if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
             if (n_edges > cap) {
@@ -811,7 +843,7 @@ class Pipeline {
                 ctx->edge_capacity = cap;
             }
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
-            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_OVF], 0, sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_OVF], 0, 5 * sizeof(unsigned long long), s)); // and the item counters
         }
         st.n_edges = n_edges;
         return UMI_OK;
@@ -1018,6 +1050,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     umi_ctx *ctx = new (std::nothrow) umi_ctx();
     if (!ctx) return fail(UMI_ERR_NOMEM, "out of host memory");
     ctx->device = device_id;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (err == hipSuccess)
         err = hipHostMalloc((void **)&ctx->h_counters, CNT_COUNT * sizeof(unsigned long long));
@@ -1036,7 +1069,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->ranges, &ctx->fkey_sorted, &ctx->perm,
+    DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->ranges, &ctx->fkey_sorted, &ctx->perm,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
                       &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
@@ -1082,16 +1115,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
             return fail(UMI_ERR_ARG, "bs_col_chunk must be a multiple of %d in %d..%d", BS_COL_TILE,
                         BS_COL_TILE, 1 << 24);
         ctx->bs_col_chunk = (uint32_t)value;
-    } else if (!strcmp(name, "bs_tab_chunk")) {
-        if (value < BS_TAB_TILE || value > (1 << 24) || value % BS_TAB_TILE)
-            return fail(UMI_ERR_ARG, "bs_tab_chunk must be a multiple of %d in %d..%d", BS_TAB_TILE,
-                        BS_TAB_TILE, 1 << 24);
-        ctx->bs_tab_chunk = (uint32_t)value;
-    } else if (!strcmp(name, "bs_tab_sub")) {
-        if (value < BS_TAB_TILE || value > (1 << 24) || value % BS_TAB_TILE)
-            return fail(UMI_ERR_ARG, "bs_tab_sub must be a multiple of %d in %d..%d", BS_TAB_TILE,
-                        BS_TAB_TILE, 1 << 24);
-        ctx->bs_tab_sub = (uint32_t)value;
+    } else if (!strcmp(name, "bs_tab_waves")) {
+        if (value < 0 || value > (1 << 20)) return fail(UMI_ERR_ARG, "bs_tab_waves must be in 0..%d", 1 << 20);
+        ctx->bs_tab_waves = (uint32_t)value;
     } else if (!strcmp(name, "bitslice")) {
         ctx->use_bitslice = value != 0;
     } else if (!strcmp(name, "ovf_capacity")) {

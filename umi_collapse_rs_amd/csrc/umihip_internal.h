@@ -33,7 +33,11 @@ enum Counter : int {
     CNT_RISES = 5,      // entries whose freq is above their predecessor's
     CNT_START_RISES = 6, // ... of which sit at the start of a bucket (the only legal place)
     CNT_OVF = 7,        // filter hits that did not fit a block's LDS queue (global overflow list)
-    CNT_COUNT = 8,
+    CNT_ITEMS = 8,      // table kernel: (row tile, column tile) items its scan found to walk ...
+    CNT_DIAG_ITEMS = 9, // ... and those on a bucket's diagonal (dense in hits; listed apart, worked off first)
+    CNT_GRAB = 10,      // next item to hand out
+    CNT_DIAG_GRAB = 11,
+    CNT_COUNT = 12,
 };
 
 // Bit-sliced kernel: one block works on rows [bucket_start + 32*group0, ...) of one
@@ -56,9 +60,7 @@ struct RangeTask {
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
 constexpr int BS_TAB_G2 = 2;    // row groups per lane of the table variant with 2 live units
-constexpr int BS_TAB_TILE = 256;       // columns it stages per step (one wave per task)
-constexpr int BS_TAB_COL_CHUNK = 4096; // default columns per task (ctx option bs_tab_chunk)
-constexpr int BS_TAB_SUB = 512;        // ... and per block (ctx option bs_tab_sub)
+constexpr int BS_TAB_TILE = 256;       // columns per work item of the table variant
 constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
 // One wave transposes 64 rows of one bucket into bit planes.
@@ -123,9 +125,22 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int prefix_units, hipStream_t s);
-// task_cols: columns per task of the list (at most); every task is run as blocks of sub_cols columns
-hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, uint32_t task_cols,
-                         uint32_t sub_cols, hipStream_t s);
+// table variant (key-sorted buckets, 32-bit keys): row tiles of 64 * BS_TAB_G2 groups, the
+// scan's list of (row tile, column tile) items to walk
+struct TabRowTile {
+    uint32_t bucket_start, bucket_end; // global entry indices
+    uint32_t group0, ngroups;          // first group of the tile, groups in the bucket
+    uint64_t plane_off;
+};
+struct TabItem {
+    uint32_t row_tile; // index into the row tile list
+    uint32_t col0;     // global index of the first column
+    uint32_t ncols;    // <= BS_TAB_TILE
+    uint32_t diag;     // some column index <= some row index (needs the row < column mask)
+};
+hipError_t launch_bs_tab(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
+                         uint32_t item_cap, int umi_len, uint32_t part, uint32_t n_parts, uint32_t n_waves,
+                         hipStream_t s);
 // exact check of the n_entries filter hits in a.ovf (the bit-sliced kernels' overflow list)
 hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries, hipStream_t s);
 

@@ -760,156 +760,258 @@ __device__ __forceinline__ u32x16 unit_table(const uint4 &q, std::integer_sequen
     return t;
 }
 
-template <int LP, int K, int LIVE, int G>
-__global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, uint32_t subs_per_task, uint32_t sub_cols)
+// rows of a group (prefix planes pp, plane j = bit j of a column's prefix bits) whose prefix unit
+// u differs from that unit of the wave-uniform prefix bits pk: the column's bits become 0 / ~0
+// masks on the scalar side
+template <int PW>
+__device__ __forceinline__ uint32_t tab_prefix_unit(const uint32_t (&pp)[PW], int u, uint32_t pk)
 {
-    constexpr int THREADS = 64;    // one wave per block: no wave waits for another one's columns
+    uint32_t m = pp[4 * u] ^ (0u - ((pk >> (4 * u)) & 1u));
+#pragma unroll
+    for (int b = 1; b < 4; b++)
+        m = BITOP3(m, pp[4 * u + b], 0u - ((pk >> (4 * u + b)) & 1u), TT_A | (TT_B ^ TT_C));
+    return m;
+}
+
+// ---- which (row tile, column tile) pairs of a key-sorted bucket the table kernel must walk ----
+// The columns of a 256-column tile share their highest bases (the bucket is sorted by key).  A tile
+// whose first and last column agree in the NA highest units (or are a few values of them apart:
+// every value in between is tried) is walked only if those units leave some row of the row tile
+// within k: mismatches are sticky, so no column of the tile can hit otherwise.  Every pair is
+// still decided by its own bits -- the high ones, which suffice.
+// One block per row tile.  Its waves first fill a bitmap over all 16^NA values of the NA highest
+// units -- "some row of the tile is within k of this prefix": the rows' planes against the value's
+// bits, the two highest units alone first (they rule out most values) -- then every thread looks
+// its column tiles up in it, and the tiles to walk are appended to the item list (one
+// reservation per block and round, so a row tile's items sit together; the tiles on the bucket's
+// diagonal go to a list of their own, from the array's end down).
+constexpr int TAB_SCAN_THREADS = 1024;
+template <int LP, int K>
+__global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, const TabRowTile *__restrict__ rts,
+                                                                    TabItem *__restrict__ items, uint32_t item_cap,
+                                                                    uint32_t part, uint32_t n_parts)
+{
+    constexpr int LIVE = 2, G = BS_TAB_G2;
+    constexpr int NP = 2 * LP, U = LP / 2, PU = U - LIVE, TILE = BS_TAB_TILE;
+    constexpr int NA = PU - 1 < 3 ? PU - 1 : 3; // units of the bitmap (the lowest prefix unit is never one)
+    constexpr bool CAN_SKIP = NA > K;           // enough units to pass k mismatches
+    constexpr bool TWO_LEVEL = NA == 3 && 2 > K;
+    constexpr int NVAL = CAN_SKIP ? 1 << (4 * NA) : 32;
+    constexpr int WAVES = TAB_SCAN_THREADS / 64;
+    constexpr uint32_t SEGS = 512; // words of 32 column tiles per reservation round
+    __shared__ uint32_t alive_bits[NVAL >= 32 ? NVAL / 32 : 1];
+    __shared__ uint32_t segmask[SEGS];
+    __shared__ uint32_t segoff[SEGS];
+    __shared__ uint32_t round_total, round_base, diag_mask;
+    const TabRowTile *__restrict__ rt = rts + blockIdx.x;
+    const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(rt->bucket_start);
+    const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(rt->bucket_end);
+    const uint32_t group0 = __builtin_amdgcn_readfirstlane(rt->group0);
+    const uint32_t ngroups = __builtin_amdgcn_readfirstlane(rt->ngroups);
+    const uint32_t *__restrict__ fkey = (const uint32_t *)a.fkey;
+    const uint32_t *__restrict__ planes = a.planes + rt->plane_off;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_rows = bucket_end - bucket_start;
+    const uint32_t r_lo = bucket_start + group0 * 32;               // columns start at the tile's first row
+    const uint32_t r_hi = min(bucket_end, r_lo + 64u * G * 32u);
+    const uint32_t n_tiles = (bucket_end - r_lo + TILE - 1) / TILE;
+    const uint32_t n_segs = (n_tiles + 31) / 32;
+
+    if (CAN_SKIP) {
+        for (uint32_t w = threadIdx.x; w < (uint32_t)(NVAL + 31) / 32; w += TAB_SCAN_THREADS) alive_bits[w] = 0;
+        __syncthreads();
+        // planes of the NA highest units of the tile's rows (every wave holds all of them)
+        uint32_t valid[G], pa[G][4 * NA];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t grp = group0 + (uint32_t)g * 64 + lane;
+            const uint32_t rb = grp * 32;
+            valid[g] = rb >= n_rows ? 0u : (n_rows - rb >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rb)) - 1u));
+#pragma unroll
+            for (int q = 0; q < NA; q++) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (grp < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp * NP + 4 * (U - NA + q));
+                pa[g][4 * q] = v.x;
+                pa[g][4 * q + 1] = v.y;
+                pa[g][4 * q + 2] = v.z;
+                pa[g][4 * q + 3] = v.w;
+            }
+        }
+        // do the units FROM .. NA-1 of the value pv (unit q = bits 4q .. 4q+3) leave a row within k?
+        auto open_after = [&](auto from_tag, uint32_t pv) {
+            constexpr int FROM = decltype(from_tag)::value;
+            uint32_t open_rows = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                auto unit = [&](int u) { return tab_prefix_unit<4 * NA>(pa[g], u, pv); };
+                if (K == 1) {
+                    uint32_t any = 0, two = 0;
+                    any_two_of_units<FROM, NA>(unit, any, two);
+                    open_rows |= ~two & valid[g];
+                } else {
+                    uint32_t sc[K + 2];
+#pragma unroll
+                    for (int l = 0; l < K + 2; l++) sc[l] = 0;
+                    count_units<K, FROM, NA>(unit, sc);
+                    open_rows |= ~sc[K + 1] & valid[g];
+                }
+            }
+            return __any(open_rows != 0);
+        };
+        constexpr uint32_t NQ = (uint32_t)NVAL / 16; // values of all units but the lowest of the NA
+        for (uint32_t q = wave; q < NQ; q += WAVES) {
+            if (TWO_LEVEL && !open_after(std::integral_constant<int, (TWO_LEVEL ? 1 : 0)>{}, q << 4)) continue;
+            uint32_t bits = 0;
+            for (uint32_t v = 0; v < 16; v++)
+                bits |= (open_after(std::integral_constant<int, 0>{}, (q << 4) | v) ? 1u : 0u) << v;
+            if (lane == 0 && bits) atomicOr(&alive_bits[q >> 1], bits << ((q & 1u) * 16));
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t seg_base = 0; seg_base < n_segs; seg_base += SEGS) {
+        const uint32_t segs_here = min(SEGS, n_segs - seg_base);
+        for (uint32_t i0 = wave * 64; i0 < segs_here * 32; i0 += TAB_SCAN_THREADS) {
+            const uint32_t tile = seg_base * 32 + i0 + lane;
+            bool walk = tile < n_tiles;
+            if (walk && CAN_SKIP) {
+                const uint32_t c = r_lo + tile * TILE;
+                const uint32_t pf = fkey[c] >> (4 * (U - NA));
+                const uint32_t pl = fkey[min(c + TILE, bucket_end) - 1u] >> (4 * (U - NA));
+                if (pl - pf <= 3u) { // (sorted: pl >= pf; more values in between than that: walk)
+                    walk = false;
+                    for (uint32_t p = pf; p <= pl; p++) walk = walk || ((alive_bits[p >> 5] >> (p & 31)) & 1u) != 0;
+                }
+            }
+            if (n_parts > 1) // a split call: this rank's share of the tiles (the same on every rank)
+                walk = walk && (blockIdx.x + tile) % n_parts == part;
+            const unsigned long long bal = __ballot(walk);
+            if (lane == 0) {
+                uint32_t m0 = (uint32_t)bal;
+                if (seg_base + i0 == 0) { // the tiles that reach below the row tile's last row: listed apart
+                    const uint32_t nd = min(32u, (r_hi - r_lo + TILE - 1) / TILE);
+                    const uint32_t dm = nd >= 32 ? 0xFFFFFFFFu : ((1u << nd) - 1u);
+                    diag_mask = m0 & dm;
+                    m0 &= ~dm;
+                }
+                segmask[i0 >> 5] = m0;
+                if ((i0 >> 5) + 1 < SEGS) segmask[(i0 >> 5) + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) { // exclusive prefix sum of the words' item counts
+            uint32_t cnt[SEGS / 64], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < SEGS / 64; q++) {
+                const uint32_t sl = lane * (SEGS / 64) + q;
+                cnt[q] = sl < segs_here ? (uint32_t)__builtin_popcount(segmask[sl]) : 0u;
+                sum += cnt[q];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if ((int)lane >= d) incl += up;
+            }
+            uint32_t off = incl - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < SEGS / 64; q++) {
+                segoff[lane * (SEGS / 64) + q] = off;
+                off += cnt[q];
+            }
+            if (lane == 63) round_total = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            round_base = (uint32_t)min(atomicAdd(&a.counters[CNT_ITEMS], (unsigned long long)round_total),
+                                       (unsigned long long)0xFFFFFFFFu);
+        __syncthreads();
+        const uint32_t base = round_base;
+        for (uint32_t idx = threadIdx.x; idx < segs_here * 32; idx += TAB_SCAN_THREADS) {
+            const uint32_t sl = idx >> 5, t = idx & 31;
+            const uint32_t m = segmask[sl];
+            if ((m >> t) & 1u) {
+                const uint64_t pos = (uint64_t)base + segoff[sl] + (uint32_t)__builtin_popcount(m & ((1u << t) - 1u));
+                const uint32_t c0 = r_lo + ((seg_base + sl) * 32 + t) * TILE;
+                if (pos < item_cap)
+                    items[pos] = TabItem{blockIdx.x, c0, min((uint32_t)TILE, bucket_end - c0), c0 < r_hi ? 1u : 0u};
+            }
+        }
+        if (seg_base == 0 && threadIdx.x < 32 && ((diag_mask >> threadIdx.x) & 1u)) { // from the list's end down
+            const unsigned long long pos = atomicAdd(&a.counters[CNT_DIAG_ITEMS], 1ull);
+            const uint32_t c0 = r_lo + threadIdx.x * TILE;
+            if (pos < item_cap)
+                items[item_cap - 1 - (uint32_t)pos] = TabItem{blockIdx.x, c0, min((uint32_t)TILE, bucket_end - c0), 1u};
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the table kernel proper: persistent waves over the item list ----------------------------
+// One wave per block (no wave waits for another one's columns), as many blocks as the chip holds;
+// the waves take items off the two lists until both are used up (see the loops at the end).
+template <int LP, int K, int LIVE, int G>
+__global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowTile *__restrict__ rts,
+                                                       const TabItem *__restrict__ items, uint32_t item_cap)
+{
+    constexpr int THREADS = 64;
     constexpr int NP = 2 * LP;
     constexpr int U = LP / 2;      // 2-base units per key
     constexpr int PU = U - LIVE;   // prefix units: state cached per column run
-    constexpr int PA = PU - 1;     // ... of which the coarse early out looks at all but the lowest
     constexpr int PW = 4 * PU;     // prefix planes per row group
-    constexpr int TILE = BS_TAB_TILE; // columns staged per step
+    constexpr int TILE = BS_TAB_TILE; // columns per item
+    constexpr uint32_t BATCH = 4;
     static_assert(LIVE >= 1 && LIVE <= 4 && PU >= 1, "table variant: 1..4 live units and a prefix");
     static_assert(LIVE == 2 && G == 2, "only the tuned shape is instantiated (launch_bs_tab)");
     static_assert(4 * PU <= 32, "prefix bits of a column in one word");
     __shared__ uint32_t runbits[TILE / 32];
-    __shared__ uint32_t ckey[TILE + 8]; // live unit values of the tile's columns (+ the group read ahead past its end)
+    __shared__ uint32_t ckey[TILE + 8]; // live unit values of the item's columns (+ the group read ahead past its end)
     __shared__ uint32_t pkey[TILE];     // their prefix bits (unit q of the prefix = bits 4q .. 4q+3)
-    __shared__ uint32_t nxt[TILE];      // first column after c that starts a run (or the tile's end)
+    __shared__ uint32_t nxt[TILE];      // first column after c that starts a run (or the item's end)
     constexpr uint32_t HITQ = 256;
     __shared__ uint2 hitq[HITQ];
     __shared__ unsigned int hitq_count;
     __shared__ EdgeStage stage;
-    // A task of the host's list is cut into subs_per_task column ranges of sub_cols, one block
-    // each: the walked share of a task varies between none and all of it, and short blocks
-    // even that out without a longer task list.
-    const BsTask *__restrict__ tp = a.bs_tasks + blockIdx.x / subs_per_task;
-    const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(tp->bucket_start);
-    const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(tp->bucket_end);
-    const uint32_t group0 = __builtin_amdgcn_readfirstlane(tp->group0);
-    const uint32_t ngroups = __builtin_amdgcn_readfirstlane(tp->ngroups);
-    const uint32_t task_col1 = __builtin_amdgcn_readfirstlane(tp->col1);
-    const uint32_t col0 = __builtin_amdgcn_readfirstlane(tp->col0) + (blockIdx.x % subs_per_task) * sub_cols;
-    if (col0 >= task_col1) return;
-    const uint32_t col1 = min(task_col1, col0 + sub_cols);
     const uint32_t *__restrict__ fkey = (const uint32_t *)a.fkey;
-    const uint32_t *__restrict__ planes = a.planes + tp->plane_off;
     const int tid = threadIdx.x;
     const bool with_dist = a.mode == MODE_NEIGHBOURS;
-    const uint32_t n_rows = bucket_end - bucket_start;
-    // some column index <= some row index: needs the row < column mask (wave-uniform)
-    const bool diag = col0 < bucket_start + (group0 + 64u * G) * 32u;
     constexpr bool EARLY = true;
-
-    uint32_t rbase[G], valid[G]; // bucket-relative index of the group's first row; its rows in range
-    uint32_t pp[G][PW];          // planes of the prefix units (plane j of the prefix = bit j of a column's pkey)
-    uint32_t grp[G];
-    auto load_quad = [&](int g, int q) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (grp[g] < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp[g] * NP + 4 * q);
-        return v;
+    const uint32_t n_items = (uint32_t)min((unsigned long long)item_cap, a.counters[CNT_ITEMS]);
+    const uint32_t n_diag = (uint32_t)min((unsigned long long)item_cap, a.counters[CNT_DIAG_ITEMS]);
+    // the next `count` items of a list (wave-uniform; >= the list's length when it is used up)
+    auto grab = [&](int counter, uint32_t count) {
+        uint32_t got = 0;
+        if (tid == 0)
+            got = (uint32_t)min((unsigned long long)0xFFFFFFFFu,
+                                atomicAdd(&a.counters[counter], (unsigned long long)count));
+        return (uint32_t)__builtin_amdgcn_readfirstlane(got); // lane 0's
     };
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        grp[g] = group0 + (uint32_t)g * THREADS + (uint32_t)tid; // the wave's 64 * G groups are adjacent
-        rbase[g] = grp[g] * 32;
-        valid[g] = rbase[g] >= n_rows ? 0u
-                   : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
-#pragma unroll
-        for (int q = 0; q < PU; q++) {
-            const uint4 v = load_quad(g, LIVE + q);
-            pp[g][4 * q] = v.x;
-            pp[g][4 * q + 1] = v.y;
-            pp[g][4 * q + 2] = v.z;
-            pp[g][4 * q + 3] = v.w;
-        }
-    }
-    // rows of group g whose prefix unit u differs from that unit of the (wave-uniform) prefix
-    // bits pk: the column's bits become 0 / ~0 masks on the scalar side
-    auto prefix_unit = [&](int g, int u, uint32_t pk) {
-        uint32_t m = pp[g][4 * u] ^ (0u - ((pk >> (4 * u)) & 1u));
-#pragma unroll
-        for (int b = 1; b < 4; b++)
-            m = BITOP3(m, pp[g][4 * u + b], 0u - ((pk >> (4 * u + b)) & 1u), TT_A | (TT_B ^ TT_C));
-        return m;
-    };
-
-    // ---- coarse early out, before anything else is set up -------------------------------
-    // The bucket is sorted by key, so the columns of a tile share their highest bases.  A tile
-    // whose first and last column agree in the PA highest units (or are a few values of them
-    // apart: every value in between is tried) is walked only if those units leave some row of the wave within k:
-    // mismatches are sticky, so no column of the tile can hit otherwise.  Every pair is still
-    // decided by its own bits -- the high ones, which suffice.
-    const uint32_t ntiles = (col1 - col0 + TILE - 1) / TILE;
-    uint32_t alive_tiles = 0xFFFFFFFFu; // bit t: tile t must be walked (tiles past 32: always)
-    if (EARLY && PA > K) {
-        uint32_t kb = 0; // lane 2t: first key of tile t, lane 2t+1: its last key
-        {
-            const uint32_t t = (uint32_t)tid >> 1, c = col0 + t * TILE;
-            if (t < ntiles && c < col1) kb = fkey[(tid & 1) ? min(c + TILE, col1) - 1u : c];
-        }
-        uint32_t seen_p = 0xFFFFFFFFu;
-        bool seen_alive = true;
-        auto prefix_alive = [&](uint32_t p) { // p = prefix bits without the lowest prefix unit
-            if (p != seen_p) {
-                uint32_t open_rows = 0;
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    auto unit = [&](int u) { return prefix_unit(g, u, p << 4); }; // u = 1 .. PU-1
-                    if (K == 1) {
-                        uint32_t any = 0, two = 0;
-                        any_two_of_units<1, PU>(unit, any, two);
-                        open_rows |= ~two & valid[g];
-                    } else {
-                        uint32_t sc[K + 2];
-#pragma unroll
-                        for (int l = 0; l < K + 2; l++) sc[l] = 0;
-                        count_units<K, 1, PU>(unit, sc);
-                        open_rows |= ~sc[K + 1] & valid[g];
-                    }
-                }
-                seen_alive = __any(open_rows != 0);
-                seen_p = p;
-            }
-            return seen_alive;
-        };
-        alive_tiles = 0;
-        const uint32_t nscan = min(ntiles, 32u);
-        for (uint32_t t = 0; t < nscan; t++) {
-            const uint32_t pf = __builtin_amdgcn_readlane(kb, 2 * t) >> (4 * (LIVE + 1));
-            const uint32_t pl = __builtin_amdgcn_readlane(kb, 2 * t + 1) >> (4 * (LIVE + 1));
-            bool alive = pl - pf > 3u; // (keys are sorted: pl >= pf; that many values in between: walk)
-            for (uint32_t p = pf; !alive && p <= pl; p++) alive = prefix_alive(p);
-            alive_tiles |= (alive ? 1u : 0u) << t;
-        }
-        if (ntiles <= 32 && alive_tiles == 0) return; // nothing of this task can hit
-    }
 
     if (tid == 0) {
         stage.count = 0;
         stage.candidates = 0;
         hitq_count = 0;
     }
+    __syncthreads();
+
+    // state of the row tile in hand
+    uint32_t cur_row_tile = 0xFFFFFFFFu;
+    uint32_t bucket_start = 0, bucket_end = 0;
+    uint32_t rbase[G] = {}, valid[G] = {};
+    uint32_t pp[G][PW] = {};     // planes of the prefix units (plane j of the prefix = bit j of a column's pkey)
     // tXY[v] = rows of group X whose live unit Y differs from value v.  Four named vectors, not
     // an array: an array of vectors this large stays in scratch memory instead of registers.
-    u32x16 t00, t01, t10, t11;
-    t00 = unit_table(load_quad(0, 0), std::make_integer_sequence<int, 16>{});
-    t01 = unit_table(load_quad(0, 1), std::make_integer_sequence<int, 16>{});
-    t10 = unit_table(load_quad(1, 0), std::make_integer_sequence<int, 16>{});
-    t11 = unit_table(load_quad(1, 1), std::make_integer_sequence<int, 16>{});
-    uint32_t pre[G][K + 2];      // counter state after the prefix units ((any, two) for K = 1)
+    u32x16 t00 = {}, t01 = {}, t10 = {}, t11 = {};
+    uint32_t pre[G][K + 2] = {}; // counter state after the prefix units ((any, two) for K = 1)
     bool dead = false;           // ... puts every row of the wave beyond k (wave-uniform)
-    bool stale = true;           // pre[] is not the state of the column before the tile's first
-#pragma unroll
-    for (int g = 0; g < G; g++)
-#pragma unroll
-        for (int l = 0; l < K + 2; l++) pre[g][l] = 0u;
+    uint32_t c0 = 0, nc = 0;
+
+    auto prefix_unit = [&](int g, int u, uint32_t pk) { return tab_prefix_unit<PW>(pp[g], u, pk); };
 
     // Exact check of the queued filter hits, one per lane: a base-level test on the two filter
     // keys first (the unit-level filter lets pairs through that differ in two bases of one
     // unit), then the reference arithmetic.  The block is one wave, so the queue can be worked
-    // off wherever the wave stands -- when it is half full, or the task ends.
+    // off wherever the wave stands -- when it is half full, or the wave is done.
     auto drain = [&](bool final) {
         __syncthreads();
         const uint32_t nq = min(hitq_count, HITQ);
@@ -917,18 +1019,241 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, uint32_t subs
             const uint2 h = hitq[i];
             if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue;
             verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
-                        a.edge_cap, a.k, a.mode, a.adj_max_freq, bucket_end, col1, h.x, h.y, a.perm);
+                        a.edge_cap, a.k, a.mode, a.adj_max_freq, 0xFFFFFFFFu, 0xFFFFFFFFu, h.x, h.y, a.perm);
         }
         __syncthreads();
         if (tid == 0) hitq_count = 0;
         flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, final);
     };
 
-    uint32_t tile_no = 0;
-    for (uint32_t c0 = col0; c0 < col1; c0 += TILE, tile_no++) {
-        const uint32_t nc = min((uint32_t)TILE, col1 - c0);
-        const bool walk = tile_no >= 32 || ((alive_tiles >> tile_no) & 1u) != 0;
-        if (walk) {
+    auto walk_columns = [&](auto diag_tag) {
+        constexpr bool DIAG = decltype(diag_tag)::value;
+        constexpr int NCOL = 4; // columns per "any hit?" test
+        auto update_prefix = [&](uint32_t c) {
+            const uint32_t pk = __builtin_amdgcn_readfirstlane(pkey[c]);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                auto unit = [&](int u) { return prefix_unit(g, u, pk); }; // u = 0 .. PU-1
+                if (K == 1) {
+                    any_two_of_units<0, PU>(unit, pre[g][0], pre[g][1]);
+                } else {
+                    uint32_t s[K + 2];
+#pragma unroll
+                    for (int l = 0; l < K + 2; l++) s[l] = 0;
+                    count_units<K, 0, PU>(unit, s);
+#pragma unroll
+                    for (int l = 0; l < K + 2; l++) pre[g][l] = s[l];
+                }
+            }
+        };
+        // rows within the filter's reach of column c, whose (sorted) key is `key`
+        auto eval_column = [&](uint32_t c, uint32_t key, uint32_t (&h)[G]) -> uint32_t {
+            uint32_t anyhit = 0;
+            uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u}, maj2[2] = {0u, 0u};
+            if (LIVE == 2 && G == 2) {
+                // The four lookups of a column under one index-mode window: the compiler
+                // brackets every indexed move with its own s_set_gpr_idx_on/off, and the one
+                // scalar unit of a CU (one instruction per 4 cycles and SIMD) is what bounds
+                // this loop.  The tables are pinned to v[64:127] for the statement.  For
+                // K = 1 the second pair of lookups is the indexed source of the majority op
+                // itself (two moves fewer per column).
+                // (m0 is rewritten by the window; the compiler never keeps a value in m0
+                // across statements, and lists it as reserved, so it is not a clobber here)
+                const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
+                const uint32_t i0 = ukey, i1 = ukey >> 8; // ckey[] holds them one per byte
+                if (K == 1) {
+                    asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "v_mov_b32 %1, v96\n\t"
+                                 "s_set_gpr_idx_idx %5\n\t"
+                                 "v_bitop3_b32 %2, v80, %6, %0 bitop3:0xe8\n\t"
+                                 "v_bitop3_b32 %3, v112, %7, %1 bitop3:0xe8\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(maj2[0]), "=&v"(maj2[1])
+                                 : "s"(i0), "s"(i1), "v"(pre[0][0]), "v"(pre[G - 1][0]), "{v[64:79]}"(t00),
+                                   "{v[80:95]}"(t01), "{v[96:111]}"(t10), "{v[112:127]}"(t11));
+                } else {
+                    asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "v_mov_b32 %1, v96\n\t"
+                                 "s_set_gpr_idx_idx %5\n\t"
+                                 "v_mov_b32 %2, v80\n\t"
+                                 "v_mov_b32 %3, v112\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(f2[0]), "=&v"(f2[1])
+                                 : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t10),
+                                   "{v[112:127]}"(t11));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                auto unit = [&](int u) {
+                    if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
+                    return 0u; // (other shapes: not instantiated)
+                };
+                uint32_t hg;
+                if (K == 1) {
+                    if (LIVE == 1) {
+                        hg = BITOP3(pre[g][1], pre[g][0] & unit(0), valid[g], ~(TT_A | TT_B) & TT_C);
+                    } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
+                        const uint32_t t = G == 2 ? maj2[g]
+                                                  : BITOP3(pre[g][0], unit(0), unit(1),
+                                                           (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                        hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                    } else {
+                        uint32_t any, two;
+                        any_two_of_units<0, LIVE>(unit, any, two);
+                        const uint32_t t = BITOP3(two, pre[g][0], any, TT_A | (TT_B & TT_C));
+                        hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
+                    }
+                } else {
+                    uint32_t s[K + 2];
+#pragma unroll
+                    for (int l = 0; l < K + 2; l++) s[l] = pre[g][l];
+                    count_units<K, 0, LIVE>(unit, s);
+                    hg = ~s[K + 1] & valid[g];
+                }
+                if (DIAG) { // only rows before the column: keeps the self pair and i > j out
+                    const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
+                    const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
+                    hg &= lt;
+                }
+                h[g] = hg;
+                anyhit |= hg;
+            }
+            return anyhit;
+        };
+        auto queue_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                uint32_t hh = h[g];
+                while (hh) {
+                    const int j = __builtin_ctz(hh);
+                    hh &= hh - 1;
+                    const uint32_t row = bucket_start + rbase[g] + j;
+                    const unsigned int slot = atomicAdd(&hitq_count, 1u);
+                    if (slot < HITQ) {
+                        hitq[slot] = make_uint2(row, c0 + c);
+                    } else { // queue full (a very dense tile): to the global overflow list,
+                             // which verify_list_kernel works off after this launch
+                        const unsigned long long pos = atomicAdd(&a.counters[CNT_OVF], 1ull);
+                        if (pos < a.ovf_cap) a.ovf[pos] = make_uint2(row, c0 + c);
+                    }
+                }
+            }
+        };
+        // run by run: new prefix state at the run's first column, then its columns in groups
+        // of NCOL (one hit test per group); the last group of a run is evaluated whole and
+        // the hit words of the columns past the run's end are dropped (their prefix state is
+        // not theirs).  The bookkeeping is wave-uniform: scalar instructions and branches.
+        // Column keys come from the LDS copy one group ahead of their use (wave-wide reads of
+        // one address, then v_readfirstlane: LDS returns in order, so the wait for a group's
+        // keys does not drain the reads issued after them; scalar loads from the key array
+        // itself would, and they miss the scalar cache every 16 columns).
+        uint32_t next[NCOL];
+        bool starts = true; // an item's first column begins a run
+        uint32_t c = 0;
+        while (c < nc) {
+            c = __builtin_amdgcn_readfirstlane(c); // (uniform already; keeps it in an SGPR)
+            if (starts) {
+                update_prefix(c);
+                // early out: when the high units alone put every row of the wave beyond k, the
+                // run's columns cannot hit (the state is sticky) -- skip their low units
+                uint32_t open_rows = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) open_rows |= ~pre[g][K == 1 ? 1 : K + 1] & valid[g];
+                dead = EARLY && !__any(open_rows != 0);
+            }
+            starts = true; // every later run of the tile begins at a flagged column
+            const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
+            if (dead) {
+                c = e;
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < NCOL; i++) next[i] = ckey[c + i];
+            for (; c + NCOL <= e; c += NCOL) { // whole groups: straight-line code
+                uint32_t key[NCOL], h[NCOL][G];
+#pragma unroll
+                for (int i = 0; i < NCOL; i++) key[i] = __builtin_amdgcn_readfirstlane(next[i]);
+#pragma unroll
+                for (int i = 0; i < NCOL; i++) next[i] = ckey[c + NCOL + i];
+                uint32_t anyhit = 0;
+#pragma unroll
+                for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i, key[i], h[i]);
+                if (__any(anyhit != 0)) {
+#pragma unroll
+                    for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
+                        drain(false);
+                }
+            }
+            if (c < e) { // the run's last 1..NCOL-1 columns: one more hit test for them
+                uint32_t h[NCOL][G];
+                const uint32_t cnt = e - c;
+                uint32_t anyhit = 0;
+#pragma unroll
+                for (int i = 0; i < NCOL - 1; i++) {
+                    if ((uint32_t)i < cnt) { // (wave-uniform)
+                        anyhit |= eval_column(c + i, __builtin_amdgcn_readfirstlane(next[i]), h[i]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; g++) h[i][g] = 0u;
+                    }
+                }
+                if (__any(anyhit != 0)) {
+#pragma unroll
+                    for (int i = 0; i < NCOL - 1; i++) queue_hits(c + i, h[i]);
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
+                        drain(false);
+                }
+                c = e;
+            }
+        }
+    };
+    auto process = [&](const TabItem &item) {
+        const uint32_t row_tile = __builtin_amdgcn_readfirstlane(item.row_tile);
+        c0 = __builtin_amdgcn_readfirstlane(item.col0);
+        nc = __builtin_amdgcn_readfirstlane(item.ncols);
+        const bool diag = __builtin_amdgcn_readfirstlane(item.diag) != 0;
+
+        if (row_tile != cur_row_tile) { // another row tile: its planes and tables
+            cur_row_tile = row_tile;
+            const TabRowTile *__restrict__ rt = rts + row_tile;
+            bucket_start = __builtin_amdgcn_readfirstlane(rt->bucket_start);
+            bucket_end = __builtin_amdgcn_readfirstlane(rt->bucket_end);
+            const uint32_t group0 = __builtin_amdgcn_readfirstlane(rt->group0);
+            const uint32_t ngroups = __builtin_amdgcn_readfirstlane(rt->ngroups);
+            const uint32_t *__restrict__ planes = a.planes + rt->plane_off;
+            const uint32_t n_rows = bucket_end - bucket_start;
+            uint32_t grp[G];
+            auto load_quad = [&](int g, int q) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (grp[g] < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp[g] * NP + 4 * q);
+                return v;
+            };
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                grp[g] = group0 + (uint32_t)g * THREADS + (uint32_t)tid; // the wave's 64 * G groups are adjacent
+                rbase[g] = grp[g] * 32;
+                valid[g] = rbase[g] >= n_rows ? 0u
+                           : (n_rows - rbase[g] >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rbase[g])) - 1u));
+#pragma unroll
+                for (int q = 0; q < PU; q++) {
+                    const uint4 v = load_quad(g, LIVE + q);
+                    pp[g][4 * q] = v.x;
+                    pp[g][4 * q + 1] = v.y;
+                    pp[g][4 * q + 2] = v.z;
+                    pp[g][4 * q + 3] = v.w;
+                }
+            }
+            t00 = unit_table(load_quad(0, 0), std::make_integer_sequence<int, 16>{});
+            t01 = unit_table(load_quad(0, 1), std::make_integer_sequence<int, 16>{});
+            t10 = unit_table(load_quad(1, 0), std::make_integer_sequence<int, 16>{});
+            t11 = unit_table(load_quad(1, 1), std::make_integer_sequence<int, 16>{});
+        }
+
+        // stage the item's columns
         __syncthreads();
         for (uint32_t cc = tid; cc < (uint32_t)TILE + 8; cc += THREADS) { // (padded array)
             // the two live unit values of the column, one per byte: s_set_gpr_idx_on / _idx take
@@ -937,12 +1262,11 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, uint32_t subs
             ckey[cc] = (kq & 15u) | (((kq >> 4) & 15u) << 8);
             if (cc < (uint32_t)TILE) pkey[cc] = kq >> (4 * LIVE);
         }
+        __syncthreads();
         for (uint32_t cc = tid; cc < (uint32_t)TILE; cc += THREADS) { // does column cc start a run of equal high bases?
-            bool newrun = false;
-            if (cc < nc) // the first column of the task, or high bases unlike the column before
-                newrun = c0 + cc == col0 || ((fkey[c0 + cc] ^ fkey[c0 + cc - 1]) >> (4 * LIVE)) != 0;
+            const bool newrun = cc < nc && (cc == 0 || pkey[cc] != pkey[cc - 1]);
             const unsigned long long bal = __ballot(newrun);
-            if ((tid & 63) == 0) {
+            if (tid == 0) {
                 runbits[2 * (cc >> 6)] = (uint32_t)bal;
                 runbits[2 * (cc >> 6) + 1] = (uint32_t)(bal >> 32);
             }
@@ -961,199 +1285,24 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, uint32_t subs
         }
         __syncthreads();
 
-        auto walk_columns = [&](auto diag_tag) {
-            constexpr bool DIAG = decltype(diag_tag)::value;
-            constexpr int NCOL = 4; // columns per "any hit?" test
-            auto update_prefix = [&](uint32_t c) {
-                const uint32_t pk = __builtin_amdgcn_readfirstlane(pkey[c]);
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    auto unit = [&](int u) { return prefix_unit(g, u, pk); }; // u = 0 .. PU-1
-                    if (K == 1) {
-                        any_two_of_units<0, PU>(unit, pre[g][0], pre[g][1]);
-                    } else {
-                        uint32_t s[K + 2];
-#pragma unroll
-                        for (int l = 0; l < K + 2; l++) s[l] = 0;
-                        count_units<K, 0, PU>(unit, s);
-#pragma unroll
-                        for (int l = 0; l < K + 2; l++) pre[g][l] = s[l];
-                    }
-                }
-            };
-            // rows within the filter's reach of column c, whose (sorted) key is `key`
-            auto eval_column = [&](uint32_t c, uint32_t key, uint32_t (&h)[G]) -> uint32_t {
-                uint32_t anyhit = 0;
-                uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u}, maj2[2] = {0u, 0u};
-                if (LIVE == 2 && G == 2) {
-                    // The four lookups of a column under one index-mode window: the compiler
-                    // brackets every indexed move with its own s_set_gpr_idx_on/off, and the one
-                    // scalar unit of a CU (one instruction per 4 cycles and SIMD) is what bounds
-                    // this loop.  The tables are pinned to v[64:127] for the statement.  For
-                    // K = 1 the second pair of lookups is the indexed source of the majority op
-                    // itself (two moves fewer per column).
-                    // (m0 is rewritten by the window; the compiler never keeps a value in m0
-                    // across statements, and lists it as reserved, so it is not a clobber here)
-                    const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
-                    const uint32_t i0 = ukey, i1 = ukey >> 8; // ckey[] holds them one per byte
-                    if (K == 1) {
-                        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
-                                     "v_mov_b32 %0, v64\n\t"
-                                     "v_mov_b32 %1, v96\n\t"
-                                     "s_set_gpr_idx_idx %5\n\t"
-                                     "v_bitop3_b32 %2, v80, %6, %0 bitop3:0xe8\n\t"
-                                     "v_bitop3_b32 %3, v112, %7, %1 bitop3:0xe8\n\t"
-                                     "s_set_gpr_idx_off"
-                                     : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(maj2[0]), "=&v"(maj2[1])
-                                     : "s"(i0), "s"(i1), "v"(pre[0][0]), "v"(pre[G - 1][0]), "{v[64:79]}"(t00),
-                                       "{v[80:95]}"(t01), "{v[96:111]}"(t10), "{v[112:127]}"(t11));
-                    } else {
-                        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
-                                     "v_mov_b32 %0, v64\n\t"
-                                     "v_mov_b32 %1, v96\n\t"
-                                     "s_set_gpr_idx_idx %5\n\t"
-                                     "v_mov_b32 %2, v80\n\t"
-                                     "v_mov_b32 %3, v112\n\t"
-                                     "s_set_gpr_idx_off"
-                                     : "=&v"(e2[0]), "=&v"(e2[1]), "=&v"(f2[0]), "=&v"(f2[1])
-                                     : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01), "{v[96:111]}"(t10),
-                                       "{v[112:127]}"(t11));
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    auto unit = [&](int u) {
-                        if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
-                        return 0u; // (other shapes: not instantiated)
-                    };
-                    uint32_t hg;
-                    if (K == 1) {
-                        if (LIVE == 1) {
-                            hg = BITOP3(pre[g][1], pre[g][0] & unit(0), valid[g], ~(TT_A | TT_B) & TT_C);
-                        } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
-                            const uint32_t t = G == 2 ? maj2[g]
-                                                      : BITOP3(pre[g][0], unit(0), unit(1),
-                                                               (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
-                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
-                        } else {
-                            uint32_t any, two;
-                            any_two_of_units<0, LIVE>(unit, any, two);
-                            const uint32_t t = BITOP3(two, pre[g][0], any, TT_A | (TT_B & TT_C));
-                            hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
-                        }
-                    } else {
-                        uint32_t s[K + 2];
-#pragma unroll
-                        for (int l = 0; l < K + 2; l++) s[l] = pre[g][l];
-                        count_units<K, 0, LIVE>(unit, s);
-                        hg = ~s[K + 1] & valid[g];
-                    }
-                    if (DIAG) { // only rows before the column: keeps the self pair and i > j out
-                        const int d = (int)(c0 + c - bucket_start) - (int)rbase[g];
-                        const uint32_t lt = d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
-                        hg &= lt;
-                    }
-                    h[g] = hg;
-                    anyhit |= hg;
-                }
-                return anyhit;
-            };
-            auto queue_hits = [&](uint32_t c, const uint32_t (&h)[G]) {
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    uint32_t hh = h[g];
-                    while (hh) {
-                        const int j = __builtin_ctz(hh);
-                        hh &= hh - 1;
-                        const uint32_t row = bucket_start + rbase[g] + j;
-                        const unsigned int slot = atomicAdd(&hitq_count, 1u);
-                        if (slot < HITQ) {
-                            hitq[slot] = make_uint2(row, c0 + c);
-                        } else { // queue full (a very dense tile): to the global overflow list,
-                                 // which verify_list_kernel works off after this launch
-                            const unsigned long long pos = atomicAdd(&a.counters[CNT_OVF], 1ull);
-                            if (pos < a.ovf_cap) a.ovf[pos] = make_uint2(row, c0 + c);
-                        }
-                    }
-                }
-            };
-            // run by run: new prefix state at the run's first column, then its columns in groups
-            // of NCOL (one hit test per group); the last group of a run is evaluated whole and
-            // the hit words of the columns past the run's end are dropped (their prefix state is
-            // not theirs).  The bookkeeping is wave-uniform: scalar instructions and branches.
-            // Column keys come from the LDS copy one group ahead of their use (wave-wide reads of
-            // one address, then v_readfirstlane: LDS returns in order, so the wait for a group's
-            // keys does not drain the reads issued after them; scalar loads from the key array
-            // itself would, and they miss the scalar cache every 16 columns).
-            uint32_t next[NCOL];
-            // is column 0 a run start?  (also after tiles this wave did not walk)
-            bool starts = stale || (__builtin_amdgcn_readfirstlane(runbits[0]) & 1u) != 0;
-            uint32_t c = 0;
-            while (c < nc) {
-                c = __builtin_amdgcn_readfirstlane(c); // (uniform already; keeps it in an SGPR)
-                if (starts) {
-                    update_prefix(c);
-                    // early out: when the high units alone put every row of the wave beyond k, the
-                    // run's columns cannot hit (the state is sticky) -- skip their low units
-                    uint32_t open_rows = 0;
-#pragma unroll
-                    for (int g = 0; g < G; g++) open_rows |= ~pre[g][K == 1 ? 1 : K + 1] & valid[g];
-                    dead = EARLY && !__any(open_rows != 0);
-                }
-                starts = true; // every later run of the tile begins at a flagged column
-                const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
-                if (dead) {
-                    c = e;
-                    continue;
-                }
-#pragma unroll
-                for (int i = 0; i < NCOL; i++) next[i] = ckey[c + i];
-                for (; c + NCOL <= e; c += NCOL) { // whole groups: straight-line code
-                    uint32_t key[NCOL], h[NCOL][G];
-#pragma unroll
-                    for (int i = 0; i < NCOL; i++) key[i] = __builtin_amdgcn_readfirstlane(next[i]);
-#pragma unroll
-                    for (int i = 0; i < NCOL; i++) next[i] = ckey[c + NCOL + i];
-                    uint32_t anyhit = 0;
-#pragma unroll
-                    for (int i = 0; i < NCOL; i++) anyhit |= eval_column(c + i, key[i], h[i]);
-                    if (__any(anyhit != 0)) {
-#pragma unroll
-                        for (int i = 0; i < NCOL; i++) queue_hits(c + i, h[i]);
-                        if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
-                            drain(false);
-                    }
-                }
-                if (c < e) { // the run's last 1..NCOL-1 columns: one more hit test for them
-                    uint32_t h[NCOL][G];
-                    const uint32_t cnt = e - c;
-                    uint32_t anyhit = 0;
-#pragma unroll
-                    for (int i = 0; i < NCOL - 1; i++) {
-                        if ((uint32_t)i < cnt) { // (wave-uniform)
-                            anyhit |= eval_column(c + i, __builtin_amdgcn_readfirstlane(next[i]), h[i]);
-                        } else {
-#pragma unroll
-                            for (int g = 0; g < G; g++) h[i][g] = 0u;
-                        }
-                    }
-                    if (__any(anyhit != 0)) {
-#pragma unroll
-                        for (int i = 0; i < NCOL - 1; i++) queue_hits(c + i, h[i]);
-                        if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
-                            drain(false);
-                    }
-                    c = e;
-                }
-            }
-        };
         if (diag) walk_columns(std::true_type{});
         else walk_columns(std::false_type{});
-        stale = false;
-        } else {
-            stale = true;
-        }
+    };
 
+    // The items on a bucket's diagonal first, one at a time (sorted neighbours: nearly all filter
+    // hits of the bucket fall there, an item takes several times as long as the others), then the
+    // rest in batches of BATCH neighbours of the list, which mostly share their row tile.  Items
+    // are handed out through a counter, the next grab is under way while an item is walked; the
+    // loops end for every wave once the lists are used up.
+    for (uint32_t cur = grab(CNT_DIAG_GRAB, 1); cur < n_diag;) {
+        const uint32_t ahead = grab(CNT_DIAG_GRAB, 1);
+        process(items[item_cap - 1 - cur]);
+        cur = ahead;
+    }
+    for (uint32_t cur = grab(CNT_GRAB, BATCH); cur < n_items;) {
+        const uint32_t ahead = grab(CNT_GRAB, BATCH);
+        for (uint32_t m = 0; m < BATCH && cur + m < n_items; m++) process(items[cur + m]);
+        cur = ahead;
     }
     drain(true);
     __syncthreads();
@@ -1983,34 +2132,39 @@ void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int 
 
 namespace {
 template <int LP, int K>
-void launch_tab_k(const PairArgs &a, uint32_t n_tasks, uint32_t subs, uint32_t sub_cols, hipStream_t s)
+void launch_tab_k(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
+                  uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, hipStream_t s)
 {
+    tab_scan_kernel<LP, K><<<n_row_tiles, TAB_SCAN_THREADS, 0, s>>>(a, rts, items, item_cap, part, n_parts);
     // two live units looked up in the tables, the other LP/2 - 2 cached per column run
-    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_tasks * subs, 64, 0, s>>>(a, subs, sub_cols); // one wave per block
+    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
 }
 template <int LP>
-void launch_tab_lp(const PairArgs &a, uint32_t n_tasks, uint32_t subs, uint32_t sub_cols, hipStream_t s)
+void launch_tab_lp(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
+                   uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_tab_k<LP, 0>(a, n_tasks, subs, sub_cols, s); break;
-    case 1: launch_tab_k<LP, 1>(a, n_tasks, subs, sub_cols, s); break;
-    case 2: launch_tab_k<LP, 2>(a, n_tasks, subs, sub_cols, s); break;
-    default: launch_tab_k<LP, 3>(a, n_tasks, subs, sub_cols, s); break;
+    case 0: launch_tab_k<LP, 0>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
+    case 1: launch_tab_k<LP, 1>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
+    case 2: launch_tab_k<LP, 2>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
+    default: launch_tab_k<LP, 3>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
     }
 }
 } // namespace
 
-// table variant: 32-bit keys, key-sorted buckets, BS_TAB_G2 row groups per lane, 2 live units
-hipError_t launch_bs_tab(const PairArgs &a, uint32_t n_tasks, int umi_len, uint32_t task_cols,
-                         uint32_t sub_cols, hipStream_t s)
+// table variant: 32-bit keys, key-sorted buckets, BS_TAB_G2 row groups per lane, 2 live units.
+// a.counters[CNT_ITEMS] must be 0; the scan fills items[] (capacity item_cap = the row tiles'
+// column tiles, all of them), n_waves persistent one-wave blocks work it off.
+hipError_t launch_bs_tab(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
+                         uint32_t item_cap, int umi_len, uint32_t part, uint32_t n_parts, uint32_t n_waves,
+                         hipStream_t s)
 {
-    if (n_tasks == 0) return hipSuccess;
+    if (n_row_tiles == 0 || item_cap == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
-    const uint32_t subs = (task_cols + sub_cols - 1) / sub_cols;
-    if ((uint64_t)n_tasks * subs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (lp == 8) launch_tab_lp<8>(a, n_tasks, subs, sub_cols, s);
-    else if (lp == 12) launch_tab_lp<12>(a, n_tasks, subs, sub_cols, s);
-    else launch_tab_lp<16>(a, n_tasks, subs, sub_cols, s);
+    n_waves = std::max(1u, std::min(n_waves, (item_cap + 3) / 4));
+    if (lp == 8) launch_tab_lp<8>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
+    else if (lp == 12) launch_tab_lp<12>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
+    else launch_tab_lp<16>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
     return hipGetLastError();
 }
 
