@@ -125,7 +125,7 @@ struct umi_ctx {
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
-    uint32_t bs_tab_waves = 0; // persistent waves of the table kernel (0: 12 per CU)
+    uint32_t bs_tab_waves = 0; // persistent waves of the table kernel (0: as many as the chip holds, 16 per CU)
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
@@ -186,7 +186,7 @@ void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
         const Plan::BsBucket &bb = pl.bs_buckets[bi];
         const uint64_t s = bb.s, e = bb.e;
         if (bb.live) { // table variant: one record per row tile
-            const uint32_t tile_groups = 64u * (uint32_t)BS_TAB_G2;
+            const uint32_t tile_groups = 64u * (uint32_t)BS_TAB_G;
             for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
                 const uint64_t r_lo = s + (uint64_t)g0 * 32;
                 pl.tab_rows.push_back(TabRowTile{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off});
@@ -800,7 +800,9 @@ class Pipeline {
             if (!pl.tab_rows.empty()) // the table variant first (the largest buckets)
                 HIP_TRY(launch_bs_tab(b, ctx->tab_rows.as<TabRowTile>(), (uint32_t)pl.tab_rows.size(),
                                       ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
-                                      n_parts, ctx->bs_tab_waves ? ctx->bs_tab_waves : 12u * (uint32_t)ctx->n_cus, s));
+                                      n_parts,
+                                      ctx->bs_tab_waves ? ctx->bs_tab_waves
+                                                        : (BS_TAB_G == 1 ? 16u : 12u) * (uint32_t)ctx->n_cus, s));
             size_t first = pl.n_bs();
             for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
                 first -= pl.bs_tasks[li].size();
@@ -835,7 +837,7 @@ class Pipeline {
             if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
                 st.n_pairs_evaluated = pl.n_pairs_eval - pl.n_pairs_eval_tab +
                                        (ctx->h_counters[CNT_ITEMS] + ctx->h_counters[CNT_DIAG_ITEMS]) *
-                                           (64ull * BS_TAB_G2 * 32) * BS_TAB_TILE;
+                                           (64ull * BS_TAB_G * 32) * BS_TAB_TILE;
             if (!redo && n_edges <= cap) break;
             if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
             if (n_edges > cap) {

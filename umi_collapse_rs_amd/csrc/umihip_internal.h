@@ -59,7 +59,7 @@ struct RangeTask {
 };
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
-constexpr int BS_TAB_G2 = 2;    // row groups per lane of the table variant with 2 live units
+constexpr int BS_TAB_G = 1;     // row groups of 32 per lane of the table variant (a wave: 64 * 32 * G rows)
 constexpr int BS_TAB_TILE = 256;       // columns per work item of the table variant
 constexpr int FUSED_MAX = 128; // largest bucket the fused one-wave kernel takes (2 rows per lane)
 
@@ -125,7 +125,7 @@ hipError_t launch_build_planes(const void *fkey2, bool key32, const PlaneTask *t
 // unit: bases per counted unit of the filter (1 = exact base count, 2 = default)
 hipError_t launch_bs_pairs(const PairArgs &a, uint32_t n_tasks, bool wide, bool key32,
                            int umi_len, int unit, int prefix_units, hipStream_t s);
-// table variant (key-sorted buckets, 32-bit keys): row tiles of 64 * BS_TAB_G2 groups, the
+// table variant (key-sorted buckets, 32-bit keys): row tiles of 64 * BS_TAB_G groups, the
 // scan's list of (row tile, column tile) items to walk
 struct TabRowTile {
     uint32_t bucket_start, bucket_end; // global entry indices

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, 
                                                                     TabItem *__restrict__ items, uint32_t item_cap,
                                                                     uint32_t part, uint32_t n_parts)
 {
-    constexpr int LIVE = 2, G = BS_TAB_G2;
+    constexpr int LIVE = 2, G = BS_TAB_G;
     constexpr int NP = 2 * LP, U = LP / 2, PU = U - LIVE, TILE = BS_TAB_TILE;
     constexpr int NA = PU - 1 < 3 ? PU - 1 : 3; // units of the bitmap (the lowest prefix unit is never one)
     constexpr bool CAN_SKIP = NA > K;           // enough units to pass k mismatches
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, 
 // One wave per block (no wave waits for another one's columns), as many blocks as the chip holds;
 // the waves take items off the two lists until both are used up (see the loops at the end).
 template <int LP, int K, int LIVE, int G>
-__global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowTile *__restrict__ rts,
+__global__ __launch_bounds__(64, G == 1 ? 4 : 3) void bs_tab_kernel(PairArgs a, const TabRowTile *__restrict__ rts,
                                                        const TabItem *__restrict__ items, uint32_t item_cap)
 {
     constexpr int THREADS = 64;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowT
     constexpr int TILE = BS_TAB_TILE; // columns per item
     constexpr uint32_t BATCH = 4;
     static_assert(LIVE >= 1 && LIVE <= 4 && PU >= 1, "table variant: 1..4 live units and a prefix");
-    static_assert(LIVE == 2 && G == 2, "only the tuned shape is instantiated (launch_bs_tab)");
+    static_assert(LIVE == 2 && (G == 1 || G == 2), "only the tuned shapes are instantiated (launch_bs_tab)");
     static_assert(4 * PU <= 32, "prefix bits of a column in one word");
     __shared__ uint32_t runbits[TILE / 32];
     __shared__ uint32_t ckey[TILE + 8]; // live unit values of the item's columns (+ the group read ahead past its end)
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowT
         auto eval_column = [&](uint32_t c, uint32_t key, uint32_t (&h)[G]) -> uint32_t {
             uint32_t anyhit = 0;
             uint32_t e2[2] = {0u, 0u}, f2[2] = {0u, 0u}, maj2[2] = {0u, 0u};
-            if (LIVE == 2 && G == 2) {
+            if (LIVE == 2) {
                 // The four lookups of a column under one index-mode window: the compiler
                 // brackets every indexed move with its own s_set_gpr_idx_on/off, and the one
                 // scalar unit of a CU (one instruction per 4 cycles and SIMD) is what bounds
@@ -1061,7 +1061,23 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowT
                 // across statements, and lists it as reserved, so it is not a clobber here)
                 const uint32_t ukey = __builtin_amdgcn_readfirstlane(key); // (already uniform)
                 const uint32_t i0 = ukey, i1 = ukey >> 8; // ckey[] holds them one per byte
-                if (K == 1) {
+                if (G == 1 && K == 1) {
+                    asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "s_set_gpr_idx_idx %3\n\t"
+                                 "v_bitop3_b32 %1, v80, %4, %0 bitop3:0xe8\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e2[0]), "=&v"(maj2[0])
+                                 : "s"(i0), "s"(i1), "v"(pre[0][0]), "{v[64:79]}"(t00), "{v[80:95]}"(t01));
+                } else if (G == 1) {
+                    asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0)\n\t"
+                                 "v_mov_b32 %0, v64\n\t"
+                                 "s_set_gpr_idx_idx %3\n\t"
+                                 "v_mov_b32 %1, v80\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "=&v"(e2[0]), "=&v"(f2[0])
+                                 : "s"(i0), "s"(i1), "{v[64:79]}"(t00), "{v[80:95]}"(t01));
+                } else if (K == 1) {
                     asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
                                  "v_mov_b32 %0, v64\n\t"
                                  "v_mov_b32 %1, v96\n\t"
@@ -1088,17 +1104,14 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowT
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 auto unit = [&](int u) {
-                    if (LIVE == 2 && G == 2) return u == 0 ? e2[g] : f2[g];
-                    return 0u; // (other shapes: not instantiated)
+                    return u == 0 ? e2[g] : f2[g];
                 };
                 uint32_t hg;
                 if (K == 1) {
                     if (LIVE == 1) {
                         hg = BITOP3(pre[g][1], pre[g][0] & unit(0), valid[g], ~(TT_A | TT_B) & TT_C);
                     } else if (LIVE == 2) { // two in all = twoP | maj(anyP, m0, m1)
-                        const uint32_t t = G == 2 ? maj2[g]
-                                                  : BITOP3(pre[g][0], unit(0), unit(1),
-                                                           (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                        const uint32_t t = maj2[g]; // maj(anyP, m0, m1), from the lookup window
                         hg = BITOP3(pre[g][1], t, valid[g], ~(TT_A | TT_B) & TT_C);
                     } else {
                         uint32_t any, two;
@@ -1249,8 +1262,10 @@ __global__ __launch_bounds__(64, 3) void bs_tab_kernel(PairArgs a, const TabRowT
             }
             t00 = unit_table(load_quad(0, 0), std::make_integer_sequence<int, 16>{});
             t01 = unit_table(load_quad(0, 1), std::make_integer_sequence<int, 16>{});
-            t10 = unit_table(load_quad(1, 0), std::make_integer_sequence<int, 16>{});
-            t11 = unit_table(load_quad(1, 1), std::make_integer_sequence<int, 16>{});
+            if (G == 2) {
+                t10 = unit_table(load_quad(G - 1, 0), std::make_integer_sequence<int, 16>{});
+                t11 = unit_table(load_quad(G - 1, 1), std::make_integer_sequence<int, 16>{});
+            }
         }
 
         // stage the item's columns
@@ -2137,7 +2152,7 @@ void launch_tab_k(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles
 {
     tab_scan_kernel<LP, K><<<n_row_tiles, TAB_SCAN_THREADS, 0, s>>>(a, rts, items, item_cap, part, n_parts);
     // two live units looked up in the tables, the other LP/2 - 2 cached per column run
-    bs_tab_kernel<LP, K, 2, BS_TAB_G2><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
+    bs_tab_kernel<LP, K, 2, BS_TAB_G><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
 }
 template <int LP>
 void launch_tab_lp(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
@@ -2152,7 +2167,7 @@ void launch_tab_lp(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tile
 }
 } // namespace
 
-// table variant: 32-bit keys, key-sorted buckets, BS_TAB_G2 row groups per lane, 2 live units.
+// table variant: 32-bit keys, key-sorted buckets, BS_TAB_G row groups per lane, 2 live units.
 // a.counters[CNT_ITEMS] must be 0; the scan fills items[] (capacity item_cap = the row tiles'
 // column tiles, all of them), n_waves persistent one-wave blocks work it off.
 hipError_t launch_bs_tab(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
