@@ -26,8 +26,11 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_CONFIG2 = (303869.2 + 35640.6) * 1024  # bytes per bs_tab_kernel launch at config 2:
-# FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v8.csv
+TRAFFIC_CONFIG2 = (372937.2 + 5264.8 + 9190.4 + 1236.7) * 1024  # bytes per launch of bs_tab_kernel +
+# tab_scan_kernel at config 2: FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v9.csv
+INSTS_CONFIG2 = 4.417e8  # wave instructions per bs_tab_kernel launch at config 2 (SQ_ACTIVE_INST_ANY,
+# profiles/r01_config2_sq_counters_v9.csv): 1.97e8 VALU, 1.74e8 scalar, 0.40e8 branch, 0.19e8 LDS
+ISSUE_PEAK = 256 * 4 * 2.4e9  # one instruction per SIMD and clock
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
 # and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
 # counter over the L'/unit units: 0.5 per unit for K = 0, K+1 per unit for K > 1, and for
@@ -281,9 +284,16 @@ def main():
         opts = {o.split("=")[0]: int(o.split("=")[1]) for o in args.opt}
         n_max = int(np.diff(st["bucket_off"].astype(np.int64)).max())
         shape = table_kernel_shape(n_max, args.umi_len, opts) if args.k <= 3 and not split else None
+        walked = None
         if shape:
-            opp = table_ops_per_pair(args.k, shape)
-            kernel_name = "bs_tab_kernel (bit-sliced filter, key-sorted columns, register tables)"
+            # the table kernel walks only the (row tile, column tile) pairs its scan keeps (those
+            # whose high bases leave a row within k): the fraction is a property of the data and
+            # of the algorithm, counted by the run itself
+            walked = min(1.0, s0["n_pairs_evaluated"] / max(w_local, 1))
+            opp_walked = table_ops_per_pair(args.k, shape)
+            opp = opp_walked * walked
+            kernel_name = ("tab_scan_kernel + bs_tab_kernel (bit-sliced filter, key-sorted columns, "
+                           "register tables, early out on the high bases)")
         else:
             opp = ops_per_pair(args.umi_len, args.k, opts.get("bs_unit", 2))
             kernel_name = "bs_pair_kernel (bit-sliced all-pairs filter)"
@@ -319,14 +329,27 @@ def main():
                 "traffic": TRAFFIC_CONFIG2 if (shape and args.config == 2 and args.reads == 1_000_000
                                                and args.umi_len == 12 and args.k == 1) else None,
                 "ops_per_pair": opp, "pairs_per_launch": w_local,
+                "walked_fraction": walked,
+                "ops_per_walked_pair": (opp / walked) if walked else None,
                 "kernel_ms": pair_ms,
                 "note": "integer VALU roofline (0 algorithmic HBM bytes per pair; no MFMA).  "
                         "achieved = ops_per_pair x W / time of the pair kernels of one step (HIP "
-                        "events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The table kernel "
-                        "needs 7x fewer lane-ops per pair than the mask kernel it replaced "
-                        "(0.134 vs 0.94 at L=12, k=1) and is bound by per-wave instruction issue "
-                        "and the scalar unit, not by VALU throughput: frac fell while pairs/s rose "
-                        "(DESIGN.md section 7).  HBM view in roofline_hbm."},
+                        "events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  ops_per_pair = "
+                        "lane-ops per walked pair x the fraction of W the kernel walks: pairs whose "
+                        "high bases already differ in more than k units are decided by those bits "
+                        "alone, a whole column tile at a time.  The kernel is bound by per-wave "
+                        "instruction issue (about half of its instructions are scalar: index-mode "
+                        "windows, loop control), not by VALU throughput: frac fell from version to "
+                        "version while pairs/s rose (DESIGN.md section 7).  HBM view in "
+                        "roofline_hbm."},
+            # the resource the table kernel is actually bound by: instructions issued per SIMD
+            # (count from the SQ counter pass in profiles/, time from this run's HIP events)
+            "roofline_issue": None if not (shape and args.config == 2 and args.reads == 1_000_000
+                                           and args.umi_len == 12 and args.k == 1) else {
+                "bound": "instruction issue", "achieved": INSTS_CONFIG2 / (max(pair_ms, 1e-6) * 1e-3) / 1e12,
+                "peak": ISSUE_PEAK / 1e12, "unit": "T wave-instructions/s",
+                "frac": INSTS_CONFIG2 / (max(pair_ms, 1e-6) * 1e-3) / ISSUE_PEAK,
+                "insts_per_launch": INSTS_CONFIG2},
             "roofline_hbm": {
                 "bound": "hbm", "achieved": BYTES_PER_UMI * n / (ms_step * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -80,9 +80,12 @@ const char *umi_last_error(void);
  * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2),
  * "bs_sorted" (0/1, default 1: buckets of >= 32768 entries are sorted by filter key on the
  * device and the tile kernels reuse the evaluation of the high bases along runs of columns
- * that agree in them -- every pair is still evaluated), "bs_tables" (0/1, default 1: with
+ * that agree in them), "bs_tables" (0/1, default 1: with
  * bs_sorted and 32-bit keys, the two lowest 2-base units of a column are looked up in
- * per-lane register tables instead of being compared plane by plane),
+ * per-lane register tables instead of being compared plane by plane, and a pair is not
+ * evaluated further once its high bases differ in more than k units -- whole column tiles
+ * and column runs at a time; n_pairs_evaluated counts what was walked), "bs_tab_waves"
+ * (persistent waves of that kernel; 0 = default, 16 per CU),
  * "two_phase" (0/1, default 1: directional collapse as connected components of the symmetric
  * pairs followed by propagation along the one-way pairs; 0 = plain label propagation over all
  * pairs, one hop per round),
