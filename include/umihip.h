@@ -85,7 +85,9 @@ const char *umi_last_error(void);
  * per-lane register tables instead of being compared plane by plane, and a pair is not
  * evaluated further once its high bases differ in more than k units -- whole column tiles
  * and column runs at a time; n_pairs_evaluated counts what was walked), "bs_tab_waves"
- * (persistent waves of that kernel; 0 = default, 16 per CU),
+ * (persistent waves of that kernel; 0 = default, 16 per CU), "bs_tab_min_run" (that kernel only
+ * for buckets where about this many sorted columns share their high bases, default 4; 0 =
+ * every bucket of >= 32768 entries),
  * "two_phase" (0/1, default 1: directional collapse as connected components of the symmetric
  * pairs followed by propagation along the one-way pairs; 0 = plain label propagation over all
  * pairs, one hop per round),

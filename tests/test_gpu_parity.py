@@ -284,6 +284,36 @@ def test_wide_sorted_buckets(L, k, n_raw, n_frac, algo, amf):
         c.close()
 
 
+@pytest.mark.parametrize("L,k,algo", [(12, 1, 0), (13, 2, 0), (16, 3, 0), (11, 0, 0), (12, 1, 1)])
+def test_table_kernel_forced_on_several_buckets(L, k, algo):
+    """bs_tab_min_run = 0 sends every bucket of >= 32768 entries with 32-bit keys through the scan +
+    table kernels, whatever the run length: three such buckets of unlike sizes (ragged last row
+    tile, last column tile of a few columns) and small ones between them in one call, against the
+    oracle and against the mask kernel."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(500 + 10 * L + k)
+    parts = []
+    for n_raw in (33500, 7, 41000, 300, 36001, 1):
+        parts.append(_wide_bucket(rng, n_raw, L, 0.001 if L == 13 else 0.0))
+    keys = np.concatenate([p[0] for p in parts])
+    nm = np.concatenate([p[1] for p in parts])
+    fr = np.concatenate([p[2] for p in parts])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint64)
+    c = umi.Context(0)
+    try:
+        c.set_option("bs_tab_min_run", 0)
+        st = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=1 if algo else 0)
+        assert st["n_pairs_evaluated"] > 0
+        nmask = nm if nm.any() else None
+        kept, root, _ = c.dedup_batch(keys, nmask, fr, off, L, k, 0.5, algo, 1 if algo else 0)
+        c.set_option("bs_tables", 0)
+        kept1, root1, st1 = c.dedup_batch(keys, nmask, fr, off, L, k, 0.5, algo, 1 if algo else 0)
+        assert (kept1 == kept).all() and (root1 == root).all()
+        assert st["n_edges"] == st1["n_edges"]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("L,k", [(12, 2), (11, 1)])
 def test_wide_sorted_bucket_dense_in_neighbours(L, k):
     """A wide bucket made of 1,000 centres with all their single-substitution variants: in

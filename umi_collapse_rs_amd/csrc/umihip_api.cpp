@@ -125,6 +125,7 @@ struct umi_ctx {
     uint32_t small_max = 1024;
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
+    uint32_t bs_tab_min_run = 4; // table variant only where a run of equal high bases is about this long
     uint32_t bs_tab_waves = 0; // persistent waves of the table kernel (0: as many as the chip holds, 16 per CU)
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
@@ -250,17 +251,17 @@ int choose_prefix_units(uint64_t n, int umi_len)
 
 // Table variant (32-bit keys): two live units, if the prefix above them (the other units' bases,
 // less the padding) still gives runs of ~4 columns; 0 otherwise.
-int choose_live_units(uint64_t n, int umi_len)
+int choose_live_units(uint64_t n, int umi_len, uint32_t min_run)
 {
     const int lp = bs_padded_len(umi_len), units = lp / 2, pad = lp - umi_len;
     if (units <= 2) return 0;
     const int bases = std::max(0, 2 * (units - 2) - pad);
-    return (n >> (2 * bases)) >= 4 ? 2 : 0;
+    return (n >> (2 * bases)) >= min_run ? 2 : 0;
 }
 
 void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
                 int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, bool tables,
-                Plan &pl)
+                uint32_t tab_min_run, Plan &pl)
 {
     pl.n_fused = 0;
     pl.ranges.clear();
@@ -310,7 +311,9 @@ void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_m
             for (uint32_t g = 0; g < ngroups; g += 2)
                 pl.plane_tasks.push_back(
                     {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
-            const int live = wide && cache_prefix && tables ? choose_live_units(n, umi_len) : 0;
+            int live = wide && cache_prefix && tables ? choose_live_units(n, umi_len, tab_min_run) : 0;
+            // (its item list is sized for the worst case, every column tile of every row tile)
+            if (live && (n / (64u * BS_TAB_G * 32u) + 1) * (n / BS_TAB_TILE + 1) / 2 > (1ull << 26)) live = 0;
             pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide,
                                      wide && cache_prefix && !live ? choose_prefix_units(n, umi_len) : 0, live});
             pl.plane_words += (uint64_t)np * ngroups;
@@ -549,7 +552,7 @@ class Pipeline {
     {
         build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
                    umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
-                   ctx->bs_tables && key32, pl);
+                   ctx->bs_tables && key32, ctx->bs_tab_min_run, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
         keep_my_share(pl.small_tasks);
         keep_my_share(pl.big_tasks);
@@ -1117,6 +1120,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
             return fail(UMI_ERR_ARG, "bs_col_chunk must be a multiple of %d in %d..%d", BS_COL_TILE,
                         BS_COL_TILE, 1 << 24);
         ctx->bs_col_chunk = (uint32_t)value;
+    } else if (!strcmp(name, "bs_tab_min_run")) {
+        if (value < 0 || value > (1 << 30)) return fail(UMI_ERR_ARG, "bs_tab_min_run must be in 0..2^30");
+        ctx->bs_tab_min_run = (uint32_t)value;
     } else if (!strcmp(name, "bs_tab_waves")) {
         if (value < 0 || value > (1 << 20)) return fail(UMI_ERR_ARG, "bs_tab_waves must be in 0..%d", 1 << 20);
         ctx->bs_tab_waves = (uint32_t)value;
