@@ -126,7 +126,9 @@ struct umi_ctx {
     bool use_bitslice = true;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
     uint32_t bs_tab_min_run = 4; // table variant only where a run of equal high bases is about this long
-    uint32_t bs_tab_waves = 0; // persistent waves of the table kernel (0: as many as the chip holds, 16 per CU)
+    bool bs_transposed = true; // table variant: walk items with the columns of a run across the lanes
+    uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 40 per CU, twice what is resident:
+                               // items are dealt statically, the dispatcher evens out the rest)
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
@@ -796,6 +798,7 @@ class Pipeline {
             a.k = k;
             a.mode = mode;
             a.adj_max_freq = adj_max_freq;
+            a.n_entries = n;
             // largest work first: wide bit-sliced tiles, column-split ones, then the popcount kernels
             PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
             b.fkey = bs_fkey;
@@ -805,7 +808,8 @@ class Pipeline {
                                       ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
                                       n_parts,
                                       ctx->bs_tab_waves ? ctx->bs_tab_waves
-                                                        : (BS_TAB_G == 1 ? 16u : 12u) * (uint32_t)ctx->n_cus, s));
+                                                        : (ctx->bs_transposed ? 40u : 16u) * (uint32_t)ctx->n_cus,
+                                      ctx->bs_transposed, s));
             size_t first = pl.n_bs();
             for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
                 first -= pl.bs_tasks[li].size();
@@ -1123,6 +1127,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "bs_tab_min_run")) {
         if (value < 0 || value > (1 << 30)) return fail(UMI_ERR_ARG, "bs_tab_min_run must be in 0..2^30");
         ctx->bs_tab_min_run = (uint32_t)value;
+    } else if (!strcmp(name, "bs_transposed")) {
+        ctx->bs_transposed = value != 0;
     } else if (!strcmp(name, "bs_tab_waves")) {
         if (value < 0 || value > (1 << 20)) return fail(UMI_ERR_ARG, "bs_tab_waves must be in 0..%d", 1 << 20);
         ctx->bs_tab_waves = (uint32_t)value;

@@ -88,6 +88,7 @@ struct PairArgs {
     uint2 *ovf;        // (row, column) of the filter hits beyond a block's LDS queue, tile indices
     uint32_t ovf_cap;
     uint32_t edge_cap;
+    uint32_t n_entries; // entries of the call (keys, fkey, ... have this many)
     int k;
     int mode;
     int32_t adj_max_freq;
@@ -140,7 +141,7 @@ struct TabItem {
 };
 hipError_t launch_bs_tab(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
                          uint32_t item_cap, int umi_len, uint32_t part, uint32_t n_parts, uint32_t n_waves,
-                         hipStream_t s);
+                         bool transposed, hipStream_t s);
 // exact check of the n_entries filter hits in a.ovf (the bit-sliced kernels' overflow list)
 hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries, hipStream_t s);
 

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, 
     __shared__ uint32_t alive_bits[NVAL >= 32 ? NVAL / 32 : 1];
     __shared__ uint32_t segmask[SEGS];
     __shared__ uint32_t segoff[SEGS];
-    __shared__ uint32_t round_total, round_base, diag_mask;
+    __shared__ uint32_t round_total, round_base;
     const TabRowTile *__restrict__ rt = rts + blockIdx.x;
     const uint32_t bucket_start = __builtin_amdgcn_readfirstlane(rt->bucket_start);
     const uint32_t bucket_end = __builtin_amdgcn_readfirstlane(rt->bucket_end);
@@ -885,16 +885,38 @@ __global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, 
             }
             if (n_parts > 1) // a split call: this rank's share of the tiles (the same on every rank)
                 walk = walk && (blockIdx.x + tile) % n_parts == part;
+            // Dense tiles -- on the bucket's diagonal, or with the highest units of some row of the
+            // tile (sorted neighbours: many rows stay open there, and nearly all filter hits fall
+            // there) -- take several times as long as the others: a list of their own, from the
+            // array's end down, worked off first.
+            bool dense = false;
+            if (walk) {
+                const uint32_t c = r_lo + tile * TILE;
+                dense = c < r_hi;
+                if (!dense && CAN_SKIP && NA >= 2) {
+                    const uint32_t qf = fkey[c] >> (4 * (U - NA + 1));
+                    dense = qf >= (fkey[r_lo] >> (4 * (U - NA + 1))) && qf <= (fkey[r_hi - 1u] >> (4 * (U - NA + 1)));
+                }
+            }
+            const unsigned long long dbal = __ballot(dense);
+            if (dbal) {
+                uint32_t dbase = 0;
+                if (lane == 0)
+                    dbase = (uint32_t)min(atomicAdd(&a.counters[CNT_DIAG_ITEMS], (unsigned long long)__builtin_popcountll(dbal)),
+                                          (unsigned long long)0xFFFFFFFFu);
+                dbase = (uint32_t)__builtin_amdgcn_readfirstlane(dbase);
+                if (dense) {
+                    const uint64_t pos = (uint64_t)dbase + (uint32_t)__builtin_popcountll(dbal & ((1ull << lane) - 1ull));
+                    const uint32_t c0 = r_lo + tile * TILE;
+                    if (pos < item_cap)
+                        items[item_cap - 1 - (uint32_t)pos] =
+                            TabItem{blockIdx.x, c0, min((uint32_t)TILE, bucket_end - c0), c0 < r_hi ? 1u : 0u};
+                }
+                walk = walk && !dense;
+            }
             const unsigned long long bal = __ballot(walk);
             if (lane == 0) {
-                uint32_t m0 = (uint32_t)bal;
-                if (seg_base + i0 == 0) { // the tiles that reach below the row tile's last row: listed apart
-                    const uint32_t nd = min(32u, (r_hi - r_lo + TILE - 1) / TILE);
-                    const uint32_t dm = nd >= 32 ? 0xFFFFFFFFu : ((1u << nd) - 1u);
-                    diag_mask = m0 & dm;
-                    m0 &= ~dm;
-                }
-                segmask[i0 >> 5] = m0;
+                segmask[i0 >> 5] = (uint32_t)bal;
                 if ((i0 >> 5) + 1 < SEGS) segmask[(i0 >> 5) + 1] = (uint32_t)(bal >> 32);
             }
         }
@@ -936,12 +958,6 @@ __global__ __launch_bounds__(TAB_SCAN_THREADS) void tab_scan_kernel(PairArgs a, 
                 if (pos < item_cap)
                     items[pos] = TabItem{blockIdx.x, c0, min((uint32_t)TILE, bucket_end - c0), c0 < r_hi ? 1u : 0u};
             }
-        }
-        if (seg_base == 0 && threadIdx.x < 32 && ((diag_mask >> threadIdx.x) & 1u)) { // from the list's end down
-            const unsigned long long pos = atomicAdd(&a.counters[CNT_DIAG_ITEMS], 1ull);
-            const uint32_t c0 = r_lo + threadIdx.x * TILE;
-            if (pos < item_cap)
-                items[item_cap - 1 - (uint32_t)pos] = TabItem{blockIdx.x, c0, min((uint32_t)TILE, bucket_end - c0), 1u};
         }
         __syncthreads();
     }
@@ -1318,6 +1334,270 @@ __global__ __launch_bounds__(64, G == 1 ? 4 : 3) void bs_tab_kernel(PairArgs a, 
         const uint32_t ahead = grab(CNT_GRAB, BATCH);
         for (uint32_t m = 0; m < BATCH && cur + m < n_items; m++) process(items[cur + m]);
         cur = ahead;
+    }
+    drain(true);
+    __syncthreads();
+    if (tid == 0 && stage.candidates)
+        atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
+}
+
+// ---- the item walk with the columns across the lanes ----------------------------------------
+// Same items, same counters as bs_tab_kernel, other shape of the inner loop.  In a walked item the
+// state after the prefix units (row-parallel: a lane = 32 rows, recomputed per run of columns with
+// equal high bases) leaves only a few rows within k -- those whose high bases all but agree with the
+// run's, one or two lanes' worth of the 2048 in the common item.  Walking every column of the run
+// against all 64 lanes spends 63 of them on rows that are already decided.  So per run the wave
+// takes the ballot of the lanes that still have an open row and, for each of them in turn, spreads
+// the run's COLUMNS over the lanes (a run is ~15 columns; longer ones go in chunks of 64): the open
+// lane's live-unit planes, counters and validity are broadcast with v_readlane (wave-uniform), each
+// lane compares them with its own column's low bits, and 32 rows x up to 64 columns are decided by
+// a dozen instructions.  No tables, no index-mode windows, no LDS in the loop.
+template <int LP, int K>
+__global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowTile *__restrict__ rts,
+                                                       const TabItem *__restrict__ items, uint32_t item_cap)
+{
+    constexpr int THREADS = 64;
+    constexpr int LIVE = 2, NP = 2 * LP, U = LP / 2, PU = U - LIVE, PW = 4 * PU, LW = 4 * LIVE;
+    constexpr int TILE = BS_TAB_TILE;
+    constexpr uint32_t BATCH = 1; // (no tables to rebuild: a change of row tile costs six plane loads)
+    static_assert(BS_TAB_G == 1, "one 32-row group per lane");
+    static_assert(PU >= 1 && 4 * PU <= 32, "prefix bits of a column in one word");
+    __shared__ uint32_t runbits[TILE / 32];
+    __shared__ uint32_t kcol[TILE];     // the item's column keys
+    __shared__ uint32_t nxt[TILE];      // first column after c that starts a run (or the item's end)
+    constexpr uint32_t HITQ = 128;
+    __shared__ uint2 hitq[HITQ];
+    __shared__ unsigned int hitq_count;
+    __shared__ EdgeStage stage;
+    const uint32_t *__restrict__ fkey = (const uint32_t *)a.fkey;
+    const int tid = threadIdx.x;
+    const bool with_dist = a.mode == MODE_NEIGHBOURS;
+    const uint32_t n_items = (uint32_t)min((unsigned long long)item_cap, a.counters[CNT_ITEMS]);
+    const uint32_t n_diag = (uint32_t)min((unsigned long long)item_cap, a.counters[CNT_DIAG_ITEMS]);
+    if (tid == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+        hitq_count = 0;
+    }
+    __syncthreads();
+
+    uint32_t cur_row_tile = 0xFFFFFFFFu;
+    uint32_t bucket_start = 0, bucket_end = 0, group0 = 0;
+    uint32_t valid = 0;
+    uint32_t pp[PW] = {}; // planes of the prefix units of the lane's 32 rows
+    uint32_t lp[LW] = {}; // ... of the two live units
+    uint32_t pre[K + 2] = {};
+
+    auto drain = [&](bool final) {
+        __syncthreads();
+        const uint32_t nq = min(hitq_count, HITQ);
+        for (uint32_t i = tid; i < nq; i += THREADS) {
+            const uint2 h = hitq[i];
+            if (filter_key_distance(fkey[h.x], fkey[h.y]) > a.k) continue; // two bases of one unit
+            verify_pair(a.keys, a.nmask, a.freq, a.thr, a.edges, a.edge_dist, a.counters, &stage,
+                        a.edge_cap, a.k, a.mode, a.adj_max_freq, 0xFFFFFFFFu, 0xFFFFFFFFu, h.x, h.y, a.perm);
+        }
+        __syncthreads();
+        if (tid == 0) hitq_count = 0;
+        flush_edges<THREADS>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, final);
+    };
+
+    constexpr int KPL = TILE / THREADS; // column keys per lane and item
+    // an item's column keys, one load per 64 columns (issued an item ahead of their use)
+    auto load_keys = [&](const TabItem &item, uint32_t (&k)[KPL]) {
+        const uint32_t col0 = __builtin_amdgcn_readfirstlane(item.col0);
+#pragma unroll
+        for (int j = 0; j < KPL; j++) k[j] = fkey[min(col0 + (uint32_t)tid + 64u * j, a.n_entries - 1u)];
+    };
+    uint32_t c0 = 0, nc = 0; // the item in hand
+    bool diag = false;
+    auto stage_item = [&](const TabItem &item, const uint32_t (&k)[KPL]) {
+        const uint32_t row_tile = __builtin_amdgcn_readfirstlane(item.row_tile);
+        c0 = __builtin_amdgcn_readfirstlane(item.col0);
+        nc = __builtin_amdgcn_readfirstlane(item.ncols);
+        diag = __builtin_amdgcn_readfirstlane(item.diag) != 0;
+        if (row_tile != cur_row_tile) { // another row tile: its planes
+            cur_row_tile = row_tile;
+            const TabRowTile *__restrict__ rt = rts + row_tile;
+            bucket_start = __builtin_amdgcn_readfirstlane(rt->bucket_start);
+            bucket_end = __builtin_amdgcn_readfirstlane(rt->bucket_end);
+            group0 = __builtin_amdgcn_readfirstlane(rt->group0);
+            const uint32_t ngroups = __builtin_amdgcn_readfirstlane(rt->ngroups);
+            const uint32_t *__restrict__ planes = a.planes + rt->plane_off;
+            const uint32_t n_rows = bucket_end - bucket_start;
+            const uint32_t grp = group0 + (uint32_t)tid;
+            const uint32_t rb = grp * 32;
+            valid = rb >= n_rows ? 0u : (n_rows - rb >= 32 ? 0xFFFFFFFFu : ((1u << (n_rows - rb)) - 1u));
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (grp < ngroups) v = *reinterpret_cast<const uint4 *>(planes + (uint64_t)grp * NP + 4 * q);
+                uint32_t *dst = q < LIVE ? &lp[4 * q] : &pp[4 * (q - LIVE)];
+                dst[0] = v.x;
+                dst[1] = v.y;
+                dst[2] = v.z;
+                dst[3] = v.w;
+            }
+        }
+
+        // Stage the item's column keys, flag the run starts (a run: neighbours that agree in the
+        // prefix units), link every column to its run's end.  The block is one wave: LDS accesses
+        // of a wave complete in order, so the compiler-level wave barriers are all that is needed --
+        // a __syncthreads() would also wait for the key loads of the next item.
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < KPL; j++) {
+            const uint32_t cc = (uint32_t)tid + 64u * j;
+            uint32_t prev = __shfl_up(k[j], 1);
+            if (tid == 0) prev = j ? (uint32_t)__builtin_amdgcn_readlane(k[j ? j - 1 : 0], 63) : ~k[0];
+            kcol[cc] = k[j];
+            const bool newrun = cc < nc && (cc == 0 || ((k[j] ^ prev) >> (4 * LIVE)) != 0);
+            const unsigned long long bal = __ballot(newrun);
+            if (tid == 0) {
+                runbits[2 * j] = (uint32_t)bal;
+                runbits[2 * j + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t cc = tid; cc < nc; cc += THREADS) {
+            uint32_t q = cc + 1, res = nc;
+            for (uint32_t w = q >> 5; w < (uint32_t)TILE / 32; w++) {
+                const uint32_t m = runbits[w] & (w == (q >> 5) ? 0xFFFFFFFFu << (q & 31) : 0xFFFFFFFFu);
+                if (m) {
+                    res = min(nc, w * 32 + (uint32_t)__builtin_ctz(m));
+                    break;
+                }
+            }
+            nxt[cc] = res;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto walk_item = [&]() {
+        for (uint32_t c = 0; c < nc;) { // run by run
+            c = __builtin_amdgcn_readfirstlane(c);
+            const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
+            const uint32_t pk = __builtin_amdgcn_readfirstlane(kcol[c]) >> (4 * LIVE);
+            { // counter state of every row after the prefix units (lane = 32 rows)
+                auto unit = [&](int u) { return tab_prefix_unit<PW>(pp, u, pk); };
+                if (K == 1) {
+                    any_two_of_units<0, PU>(unit, pre[0], pre[1]);
+                } else {
+#pragma unroll
+                    for (int l = 0; l < K + 2; l++) pre[l] = 0;
+                    count_units<K, 0, PU>(unit, pre);
+                }
+            }
+            const uint32_t open_rows = ~pre[K == 1 ? 1 : K + 1] & valid;
+            unsigned long long open_lanes = __ballot(open_rows != 0); // (wave-uniform)
+            if (open_lanes) {
+                for (uint32_t cs = c; cs < e; cs += THREADS) { // the run's columns across the lanes
+                    const uint32_t col = cs + (uint32_t)tid;   // this lane's column (if < e)
+                    const uint32_t kq = kcol[min(col, (uint32_t)TILE - 1u)];
+                    uint32_t cm[LW]; // its live bits as 0 / ~0 masks
+#pragma unroll
+                    for (int b = 0; b < LW; b++) cm[b] = 0u - ((kq >> b) & 1u);
+                    const uint32_t gcol = c0 + col - bucket_start; // bucket-relative column index
+                    for (unsigned long long todo = open_lanes; todo;) {
+                        const int la = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        auto unit = [&](int u) { // rows of lane la whose live unit u differs from this column's
+                            uint32_t m = (uint32_t)__builtin_amdgcn_readlane(lp[4 * u], la) ^ cm[4 * u];
+#pragma unroll
+                            for (int b = 1; b < 4; b++)
+                                m = BITOP3(m, (uint32_t)__builtin_amdgcn_readlane(lp[4 * u + b], la), cm[4 * u + b],
+                                           TT_A | (TT_B ^ TT_C));
+                            return m;
+                        };
+                        uint32_t hg;
+                        const uint32_t va = (uint32_t)__builtin_amdgcn_readlane(valid, la);
+                        if (K == 1) {
+                            const uint32_t any_a = (uint32_t)__builtin_amdgcn_readlane(pre[0], la);
+                            const uint32_t two_a = (uint32_t)__builtin_amdgcn_readlane(pre[1], la);
+                            const uint32_t t = BITOP3(any_a, unit(0), unit(1), (TT_A & TT_B) | (TT_A & TT_C) | (TT_B & TT_C));
+                            hg = ~two_a & ~t & va;
+                        } else {
+                            uint32_t sc[K + 2];
+#pragma unroll
+                            for (int l = 0; l < K + 2; l++) sc[l] = (uint32_t)__builtin_amdgcn_readlane(pre[l], la);
+                            count_units<K, 0, LIVE>(unit, sc);
+                            hg = ~sc[K + 1] & va;
+                        }
+                        const uint32_t rbase = (group0 + (uint32_t)la) * 32; // first row of lane la
+                        if (diag) { // only rows before the column: keeps the self pair and i > j out
+                            const int d = (int)gcol - (int)rbase;
+                            hg &= d <= 0 ? 0u : (d >= 32 ? 0xFFFFFFFFu : ((1u << d) - 1u));
+                        }
+                        if (col >= e) hg = 0;
+                        if (__any(hg != 0)) {
+                            while (hg) {
+                                const int j = __builtin_ctz(hg);
+                                hg &= hg - 1;
+                                const unsigned int slot = atomicAdd(&hitq_count, 1u);
+                                const uint2 hit = make_uint2(bucket_start + rbase + (uint32_t)j, c0 + col);
+                                if (slot < HITQ) {
+                                    hitq[slot] = hit;
+                                } else { // queue full: to the global overflow list
+                                    const unsigned long long pos = atomicAdd(&a.counters[CNT_OVF], 1ull);
+                                    if (pos < a.ovf_cap) a.ovf[pos] = hit;
+                                }
+                            }
+                            if ((uint32_t)__builtin_amdgcn_readfirstlane(*(volatile unsigned int *)&hitq_count) >= HITQ / 2)
+                                drain(false);
+                        }
+                    }
+                }
+            }
+            c = e;
+        }
+    };
+
+    // The items on a bucket's diagonal first, one at a time (sorted neighbours: nearly all filter
+    // hits of the bucket fall there, an item takes several times as long as the others), then the
+    // rest in batches of BATCH neighbours of the list, which mostly share their row tile.  Both
+    // lists are dealt round-robin over the waves (no hand-out counter: one hot word takes ~90
+    // atomics/us, tens of thousands of grabs cost more than the imbalance they remove); pull()
+    // walks this wave's share and ends with NONE for every wave.  The loop runs two items ahead with the records
+    // and one ahead with the column keys: they are loaded once the keys in hand are in LDS, so
+    // that the walk never waits for memory.
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t phase = 0, b_cur = blockIdx.x, b_pos = 0; // b_cur: batch index within the phase's list
+    auto pull = [&]() -> uint32_t {
+        for (;;) {
+            const uint32_t n_list = phase ? n_items : n_diag, bs = phase ? BATCH : 1u;
+            const uint64_t first = (uint64_t)b_cur * bs;
+            if (first + b_pos < n_list && b_pos < bs) {
+                const uint32_t idx = (uint32_t)first + b_pos++;
+                return phase ? idx : item_cap - 1 - idx;
+            }
+            if (first < n_list) { // the batch is done: this wave's next one
+                b_cur += gridDim.x;
+                b_pos = 0;
+            } else if (phase == 0) { // the diagonal list is used up
+                phase = 1;
+                b_cur = blockIdx.x;
+                b_pos = 0;
+            } else {
+                return NONE;
+            }
+        }
+    };
+    const TabItem none_item = {0u, 0u, 0u, 0u};
+    uint32_t i0 = pull(), i1 = pull();
+    TabItem rec0 = i0 != NONE ? items[i0] : none_item, rec1 = i1 != NONE ? items[i1] : none_item;
+    uint32_t k0[KPL] = {}, k1[KPL] = {};
+    if (i0 != NONE) load_keys(rec0, k0);
+    while (i0 != NONE) {
+        const uint32_t i2 = pull();
+        const TabItem rec2 = i2 != NONE ? items[i2] : none_item;
+        stage_item(rec0, k0);
+        if (i1 != NONE) load_keys(rec1, k1); // under way while this item is walked
+        walk_item();
+        i0 = i1;
+        rec0 = rec1;
+#pragma unroll
+        for (int j = 0; j < KPL; j++) k0[j] = k1[j];
+        i1 = i2;
+        rec1 = rec2;
     }
     drain(true);
     __syncthreads();
@@ -2148,21 +2428,25 @@ void launch_bs_lp(const PairArgs &a, uint32_t n_tasks, bool wide, int unit, int 
 namespace {
 template <int LP, int K>
 void launch_tab_k(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
-                  uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, hipStream_t s)
+                  uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, bool transposed,
+                  hipStream_t s)
 {
     tab_scan_kernel<LP, K><<<n_row_tiles, TAB_SCAN_THREADS, 0, s>>>(a, rts, items, item_cap, part, n_parts);
-    // two live units looked up in the tables, the other LP/2 - 2 cached per column run
-    bs_tab_kernel<LP, K, 2, BS_TAB_G><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
+    if (transposed) // columns of a run across the lanes, open row lanes one by one
+        bs_run_kernel<LP, K><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
+    else // two live units looked up in register tables, every column against all rows
+        bs_tab_kernel<LP, K, 2, BS_TAB_G><<<n_waves, 64, 0, s>>>(a, rts, items, item_cap);
 }
 template <int LP>
 void launch_tab_lp(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
-                   uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, hipStream_t s)
+                   uint32_t item_cap, uint32_t part, uint32_t n_parts, uint32_t n_waves, bool transposed,
+                   hipStream_t s)
 {
     switch (a.k) {
-    case 0: launch_tab_k<LP, 0>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
-    case 1: launch_tab_k<LP, 1>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
-    case 2: launch_tab_k<LP, 2>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
-    default: launch_tab_k<LP, 3>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s); break;
+    case 0: launch_tab_k<LP, 0>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s); break;
+    case 1: launch_tab_k<LP, 1>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s); break;
+    case 2: launch_tab_k<LP, 2>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s); break;
+    default: launch_tab_k<LP, 3>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s); break;
     }
 }
 } // namespace
@@ -2172,14 +2456,14 @@ void launch_tab_lp(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tile
 // column tiles, all of them), n_waves persistent one-wave blocks work it off.
 hipError_t launch_bs_tab(const PairArgs &a, const TabRowTile *rts, uint32_t n_row_tiles, TabItem *items,
                          uint32_t item_cap, int umi_len, uint32_t part, uint32_t n_parts, uint32_t n_waves,
-                         hipStream_t s)
+                         bool transposed, hipStream_t s)
 {
     if (n_row_tiles == 0 || item_cap == 0) return hipSuccess;
     const int lp = bs_padded_len(umi_len);
     n_waves = std::max(1u, std::min(n_waves, (item_cap + 3) / 4));
-    if (lp == 8) launch_tab_lp<8>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
-    else if (lp == 12) launch_tab_lp<12>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
-    else launch_tab_lp<16>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, s);
+    if (lp == 8) launch_tab_lp<8>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s);
+    else if (lp == 12) launch_tab_lp<12>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s);
+    else launch_tab_lp<16>(a, rts, n_row_tiles, items, item_cap, part, n_parts, n_waves, transposed, s);
     return hipGetLastError();
 }
 
