@@ -127,8 +127,8 @@ struct umi_ctx {
     uint32_t bs_col_chunk = BS_COL_CHUNK;
     uint32_t bs_tab_min_run = 4; // table variant only where a run of equal high bases is about this long
     bool bs_transposed = true; // table variant: walk items with the columns of a run across the lanes
-    uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 40 per CU, twice what is resident:
-                               // items are dealt statically, the dispatcher evens out the rest)
+    uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 128 per CU; items are dealt
+                               // statically over them, the dispatcher evens out the rest)
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
@@ -808,7 +808,7 @@ class Pipeline {
                                       ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
                                       n_parts,
                                       ctx->bs_tab_waves ? ctx->bs_tab_waves
-                                                        : (ctx->bs_transposed ? 40u : 16u) * (uint32_t)ctx->n_cus,
+                                                        : (ctx->bs_transposed ? 128u : 16u) * (uint32_t)ctx->n_cus,
                                       ctx->bs_transposed, s));
             size_t first = pl.n_bs();
             for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order

@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
     constexpr int THREADS = 64;
     constexpr int LIVE = 2, NP = 2 * LP, U = LP / 2, PU = U - LIVE, PW = 4 * PU, LW = 4 * LIVE;
     constexpr int TILE = BS_TAB_TILE;
-    constexpr uint32_t BATCH = 1; // (no tables to rebuild: a change of row tile costs six plane loads)
+    constexpr uint32_t BATCH = 4; // ordinary items per turn: neighbours of the list, mostly one row tile
     static_assert(BS_TAB_G == 1, "one 32-row group per lane");
     static_assert(PU >= 1 && 4 * PU <= 32, "prefix bits of a column in one word");
     __shared__ uint32_t runbits[TILE / 32];
@@ -1387,6 +1387,8 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
     uint32_t pp[PW] = {}; // planes of the prefix units of the lane's 32 rows
     uint32_t lp[LW] = {}; // ... of the two live units
     uint32_t pre[K + 2] = {};
+    uint32_t hi[K + 2] = {}; // state after the prefix units above the lowest, for the high bits hi_bits
+    uint32_t hi_bits = 0xFFFFFFFFu;
 
     auto drain = [&](bool final) {
         __syncthreads();
@@ -1418,6 +1420,7 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
         diag = __builtin_amdgcn_readfirstlane(item.diag) != 0;
         if (row_tile != cur_row_tile) { // another row tile: its planes
             cur_row_tile = row_tile;
+            hi_bits = 0xFFFFFFFFu;
             const TabRowTile *__restrict__ rt = rts + row_tile;
             bucket_start = __builtin_amdgcn_readfirstlane(rt->bucket_start);
             bucket_end = __builtin_amdgcn_readfirstlane(rt->bucket_end);
@@ -1477,14 +1480,28 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
             c = __builtin_amdgcn_readfirstlane(c);
             const uint32_t e = __builtin_amdgcn_readfirstlane(nxt[c]);
             const uint32_t pk = __builtin_amdgcn_readfirstlane(kcol[c]) >> (4 * LIVE);
-            { // counter state of every row after the prefix units (lane = 32 rows)
+            { // counter state of every row after the prefix units (lane = 32 rows).  Sorted keys:
+              // from one run to the next mostly the lowest prefix unit alone changes, so the state
+              // of the units above it is kept (hi[], for the bits hi_bits) and only that unit is redone
                 auto unit = [&](int u) { return tab_prefix_unit<PW>(pp, u, pk); };
+                if (PU >= 2 && (pk >> 4) != hi_bits) { // (wave-uniform)
+                    hi_bits = pk >> 4;
+                    if (K == 1) {
+                        any_two_of_units<1, PU>(unit, hi[0], hi[1]);
+                    } else {
+#pragma unroll
+                        for (int l = 0; l < K + 2; l++) hi[l] = 0;
+                        count_units<K, 1, PU>(unit, hi);
+                    }
+                }
+                const uint32_t m0 = unit(0);
                 if (K == 1) {
-                    any_two_of_units<0, PU>(unit, pre[0], pre[1]);
+                    pre[1] = PU >= 2 ? BITOP3(hi[1], hi[0], m0, TT_A | (TT_B & TT_C)) : 0u;
+                    pre[0] = PU >= 2 ? (hi[0] | m0) : m0;
                 } else {
 #pragma unroll
-                    for (int l = 0; l < K + 2; l++) pre[l] = 0;
-                    count_units<K, 0, PU>(unit, pre);
+                    for (int l = 0; l < K + 2; l++) pre[l] = PU >= 2 ? hi[l] : 0u;
+                    count_units<K, 0, 1>([&](int) { return m0; }, pre);
                 }
             }
             const uint32_t open_rows = ~pre[K == 1 ? 1 : K + 1] & valid;
@@ -1551,14 +1568,15 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
         }
     };
 
-    // The items on a bucket's diagonal first, one at a time (sorted neighbours: nearly all filter
-    // hits of the bucket fall there, an item takes several times as long as the others), then the
-    // rest in batches of BATCH neighbours of the list, which mostly share their row tile.  Both
-    // lists are dealt round-robin over the waves (no hand-out counter: one hot word takes ~90
-    // atomics/us, tens of thousands of grabs cost more than the imbalance they remove); pull()
-    // walks this wave's share and ends with NONE for every wave.  The loop runs two items ahead with the records
-    // and one ahead with the column keys: they are loaded once the keys in hand are in LDS, so
-    // that the walk never waits for memory.
+    // The dense items first, one at a time (they take several times as long as the others), then
+    // the rest in batches of BATCH neighbours of the list, which mostly share their row tile.
+    // Both lists are dealt round-robin over the blocks (no hand-out counter: one hot word takes
+    // ~90 atomics/us, tens of thousands of grabs cost more than the imbalance they remove), and
+    // the grid is large enough that a block gets one dense item and one batch at most at config-2
+    // sizes: the dispatcher then evens out what is left (blocks with nothing to do exit at
+    // once).  pull() walks this block's share and ends with NONE for every block.  The loop runs
+    // two items ahead with the records and one ahead with the column keys: they are loaded once
+    // the keys in hand are in LDS, so that the walk never waits for memory.
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t phase = 0, b_cur = blockIdx.x, b_pos = 0; // b_cur: batch index within the phase's list
     auto pull = [&]() -> uint32_t {
