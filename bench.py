@@ -26,10 +26,11 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_CONFIG2 = (372937.2 + 5264.8 + 9190.4 + 1236.7) * 1024  # bytes per launch of bs_tab_kernel +
-# tab_scan_kernel at config 2: FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v9.csv
-INSTS_CONFIG2 = 4.417e8  # wave instructions per bs_tab_kernel launch at config 2 (SQ_ACTIVE_INST_ANY,
-# profiles/r01_config2_sq_counters_v9.csv): 1.97e8 VALU, 1.74e8 scalar, 0.40e8 branch, 0.19e8 LDS
+TRAFFIC_CONFIG2 = (394627.0 + 5263.9 + 8881.9 + 1243.5) * 1024  # bytes per launch of bs_run_kernel +
+# tab_scan_kernel at config 2: FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v11.csv
+# wave instructions per bs_run_kernel launch at config 2 (profiles/r01_config2_sq_counters_v11.csv):
+VALU_INSTS_CONFIG2 = 1.606e8
+INSTS_CONFIG2 = 1.606e8 + 0.917e8 + 0.324e8 + 0.077e8 + 0.022e8  # + scalar, branch, LDS, VMEM
 ISSUE_PEAK = 256 * 4 * 2.4e9  # one instruction per SIMD and clock
 # Algorithmic VALU lane-ops per pair of the dominant kernel (bit-sliced filter): per column
 # and 32-row group, 2 full-rate 32-bit ops per base for the unit mismatch masks plus the
@@ -285,20 +286,29 @@ def main():
         n_max = int(np.diff(st["bucket_off"].astype(np.int64)).max())
         shape = table_kernel_shape(n_max, args.umi_len, opts) if args.k <= 3 and not split else None
         walked = None
+        std_cfg2 = (args.config == 2 and args.reads == 1_000_000 and args.umi_len == 12 and args.k == 1
+                    and not opts)
         if shape:
-            # the table kernel walks only the (row tile, column tile) pairs its scan keeps (those
+            # the item walk covers only the (row tile, column tile) pairs its scan keeps (those
             # whose high bases leave a row within k): the fraction is a property of the data and
             # of the algorithm, counted by the run itself
             walked = min(1.0, s0["n_pairs_evaluated"] / max(w_local, 1))
-            opp_walked = table_ops_per_pair(args.k, shape)
-            opp = opp_walked * walked
-            kernel_name = ("tab_scan_kernel + bs_tab_kernel (bit-sliced filter, key-sorted columns, "
-                           "register tables, early out on the high bases)")
+            if opts.get("bs_transposed", 1):
+                # bs_run_kernel: its work is per column run and open row lane, not per pair; the
+                # lane-ops are the VALU instructions its launch executes (SQ counter pass of the
+                # same command in profiles/, x 64 lanes) -- an upper bound of the algorithmic ones
+                opp = VALU_INSTS_CONFIG2 * 64 / w_local if std_cfg2 else None
+                kernel_name = ("tab_scan_kernel + bs_run_kernel (bit-sliced filter on key-sorted columns: "
+                               "early out on the high bases, columns of a run across the lanes)")
+            else:
+                opp = table_ops_per_pair(args.k, shape) * walked
+                kernel_name = ("tab_scan_kernel + bs_tab_kernel (bit-sliced filter, key-sorted columns, "
+                               "register tables, early out on the high bases)")
         else:
             opp = ops_per_pair(args.umi_len, args.k, opts.get("bs_unit", 2))
             kernel_name = "bs_pair_kernel (bit-sliced all-pairs filter)"
         # --split: each rank's pair kernels cover 1/world of W
-        achieved = opp * (w_local / world if split else w_local) / (max(pair_ms, 1e-6) * 1e-3) / 1e12
+        achieved = None if opp is None else opp * (w_local / world if split else w_local) / (max(pair_ms, 1e-6) * 1e-3) / 1e12
         out = {
             "metric": "UMI-pair Hamming comparisons/s (12-bp UMIs, all-pairs adjacency + "
                       "directional collapse)",
@@ -322,30 +332,29 @@ def main():
             "roofline": {
                 "bound": "valu", "kernel": kernel_name,
                 "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
-                "frac": achieved / VALU_PEAK_TLANEOPS,
+                "frac": None if achieved is None else achieved / VALU_PEAK_TLANEOPS,
                 # fabric-side bytes of one pair-kernel launch at config 2 from the PMC passes in
                 # profiles/ ((FETCH_SIZE+WRITE_SIZE)*1024, uncorrected: 4 B/lane accesses, see
                 # profiles/README.md); other shapes: null
-                "traffic": TRAFFIC_CONFIG2 if (shape and args.config == 2 and args.reads == 1_000_000
-                                               and args.umi_len == 12 and args.k == 1) else None,
+                "traffic": TRAFFIC_CONFIG2 if (shape and std_cfg2) else None,
                 "ops_per_pair": opp, "pairs_per_launch": w_local,
                 "walked_fraction": walked,
-                "ops_per_walked_pair": (opp / walked) if walked else None,
+                "ops_per_walked_pair": (opp / walked) if (walked and opp is not None) else None,
                 "kernel_ms": pair_ms,
                 "note": "integer VALU roofline (0 algorithmic HBM bytes per pair; no MFMA).  "
-                        "achieved = ops_per_pair x W / time of the pair kernels of one step (HIP "
-                        "events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  ops_per_pair = "
-                        "lane-ops per walked pair x the fraction of W the kernel walks: pairs whose "
-                        "high bases already differ in more than k units are decided by those bits "
-                        "alone, a whole column tile at a time.  The kernel is bound by per-wave "
-                        "instruction issue (about half of its instructions are scalar: index-mode "
-                        "windows, loop control), not by VALU throughput: frac fell from version to "
-                        "version while pairs/s rose (DESIGN.md section 7).  HBM view in "
-                        "roofline_hbm."},
+                        "achieved = lane-ops of one launch / time of the pair kernels of one step "
+                        "(HIP events); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The kernel "
+                        "decides a pair from its high bases where they already differ in more than "
+                        "k units (whole column tiles and column runs at a time) and walks the rest "
+                        "(walked_fraction of W, counted by the run) with the columns of a run "
+                        "across the lanes; its lane-ops are the VALU instructions of the launch "
+                        "(SQ counters, profiles/) x 64.  It is bound by dependent-instruction "
+                        "latency and instruction issue at 5 waves per SIMD, not by VALU throughput "
+                        "(DESIGN.md section 7); frac fell from version to version while pairs/s "
+                        "rose.  HBM view in roofline_hbm."},
             # the resource the table kernel is actually bound by: instructions issued per SIMD
             # (count from the SQ counter pass in profiles/, time from this run's HIP events)
-            "roofline_issue": None if not (shape and args.config == 2 and args.reads == 1_000_000
-                                           and args.umi_len == 12 and args.k == 1) else {
+            "roofline_issue": None if not (shape and std_cfg2) else {
                 "bound": "instruction issue", "achieved": INSTS_CONFIG2 / (max(pair_ms, 1e-6) * 1e-3) / 1e12,
                 "peak": ISSUE_PEAK / 1e12, "unit": "T wave-instructions/s",
                 "frac": INSTS_CONFIG2 / (max(pair_ms, 1e-6) * 1e-3) / ISSUE_PEAK,

@@ -84,8 +84,9 @@ const char *umi_last_error(void);
  * bs_sorted and 32-bit keys, the two lowest 2-base units of a column are looked up in
  * per-lane register tables instead of being compared plane by plane, and a pair is not
  * evaluated further once its high bases differ in more than k units -- whole column tiles
- * and column runs at a time; n_pairs_evaluated counts what was walked), "bs_tab_waves"
- * (persistent waves of that kernel; 0 = default, 16 per CU), "bs_tab_min_run" (that kernel only
+ * and column runs at a time; n_pairs_evaluated counts what was walked), "bs_transposed"
+ * (0/1, default 1: walk those items with the columns of a run across the lanes instead of the
+ * register tables), "bs_tab_waves" (one-wave blocks of that walk; 0 = default, 128 per CU), "bs_tab_min_run" (that kernel only
  * for buckets where about this many sorted columns share their high bases, default 4; 0 =
  * every bucket of >= 32768 entries),
  * "two_phase" (0/1, default 1: directional collapse as connected components of the symmetric

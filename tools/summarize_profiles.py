@@ -33,7 +33,7 @@ with open("profiles/r01_config2_pmc_fetch_write_%s.csv" % tag, "w", newline="") 
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_pu/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "bs_tab_kernel" in r["Kernel_Name"] or "tab_scan_kernel" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("bs_tab_kernel", "bs_run_kernel", "tab_scan_kernel")):
             acc[(r["Kernel_Name"][:150], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open("profiles/r01_config2_sq_counters_%s.csv" % tag, "w", newline="") as f:
     w = csv.writer(f)
