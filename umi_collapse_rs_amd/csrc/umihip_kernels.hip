@@ -729,17 +729,20 @@ __global__ __launch_bounds__(256) void bs_pair_kernel(PairArgs a)
         atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)stage.candidates);
 }
 
-// ---- table variant of the bit-sliced filter (key-sorted buckets, 32-bit keys) -------
-// The mask "rows whose 2-base unit u differs from value v" depends on the rows only, so for
-// the LIVE lowest units a lane keeps all 16 of them in registers (one table of 16 words per
-// unit, built once per row tile: two bitop3 per entry).  A column then selects its LIVE entries
-// with its own unit values as the index -- wave-uniform, read from the sorted key array with a
-// scalar load -- and merges them with the cached state of the PU = U - LIVE high units, which is
-// recomputed from LDS masks only where a column's high bases differ from its predecessor's.
-// The common column costs LIVE register-indexed moves and two or three bitop3 and touches no
-// LDS: the mask formulation above it is bound by the LDS return path (1 KB per 128-bit
-// broadcast read and wave, ~30 cycles per read and SIMD when all four SIMDs pull), not by VALU.
-// One row group per lane (the tables take the registers a second group's planes had).
+// ---- key-sorted buckets with 32-bit keys: scan + item walk -----------------------------------
+// A bucket sorted by filter key is cut into row tiles (one wave: 64 lanes x 32 rows x BS_TAB_G) and
+// 256-column tiles; tab_scan_kernel lists the (row tile, column tile) items that can hold a pair
+// within k at all, and one of two kernels walks them:
+//  * bs_run_kernel (default): per run of columns with equal high bases, the lanes that still have
+//    an open row are handled one by one with the run's columns spread over the lanes;
+//  * bs_tab_kernel (bs_transposed = 0): every column against all rows.  The mask "rows whose
+//    2-base unit u differs from value v" depends on the rows only, so for the LIVE lowest units a
+//    lane keeps all 16 of them in registers (one table of 16 words per unit, built once per row
+//    tile: two bitop3 per entry).  A column selects its LIVE entries with its own unit values as
+//    the index (wave-uniform, s_set_gpr_idx windows) and merges them with the cached state of the
+//    PU = U - LIVE high units.  The common column costs LIVE register-indexed operands and two
+//    bitop3 and touches no LDS: the mask formulation above is bound by the LDS return path (1 KB
+//    per 128-bit broadcast read and wave), not by VALU.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 // rows whose unit (planes q.x .. q.w) differs from the 4-bit value V:
