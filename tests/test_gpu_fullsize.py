@@ -104,15 +104,16 @@ def test_config2_one_million_reads_single_position(ctx):
 
 @pytest.mark.parametrize("L,k,n_reads", [(13, 1, 1_300_000), (12, 2, 600_000), (11, 0, 500_000)])
 def test_table_kernel_against_the_other_tile_kernels(L, k, n_reads):
-    """Deep positions the oracle cannot walk in test time: the key-sorted table kernel (also its
-    16-base shape, which needs > 10^6 entries to be chosen), the key-sorted mask kernel and the
-    unsorted one must agree bit for bit, and the result must be a fixed point (P2)."""
+    """Deep positions the oracle cannot walk in test time: the two item walks over the key-sorted
+    bucket (columns of a run across the lanes; register tables -- also in their 16-base shape,
+    which needs > 10^6 entries to be chosen), the key-sorted mask kernel and the unsorted one must
+    agree bit for bit, and the result must be a fixed point (P2)."""
     import umi_collapse_rs_amd as umi
     from umi_collapse_rs_amd import synth
     st = synth.config2(seed=40 + L, n_reads=n_reads, umi_len=L)
     keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
     outs = []
-    for opts in ({}, {"bs_tables": 0}, {"bs_sorted": 0}):
+    for opts in ({}, {"bs_transposed": 0}, {"bs_tables": 0}, {"bs_sorted": 0}):
         c = umi.Context(0)
         try:
             for name, v in opts.items():

@@ -306,10 +306,11 @@ def test_table_kernel_forced_on_several_buckets(L, k, algo):
         assert st["n_pairs_evaluated"] > 0
         nmask = nm if nm.any() else None
         kept, root, _ = c.dedup_batch(keys, nmask, fr, off, L, k, 0.5, algo, 1 if algo else 0)
-        c.set_option("bs_tables", 0)
-        kept1, root1, st1 = c.dedup_batch(keys, nmask, fr, off, L, k, 0.5, algo, 1 if algo else 0)
-        assert (kept1 == kept).all() and (root1 == root).all()
-        assert st["n_edges"] == st1["n_edges"]
+        for name in ("bs_transposed", "bs_tables"): # the table walk of the same items; the mask kernel
+            c.set_option(name, 0)
+            kept1, root1, st1 = c.dedup_batch(keys, nmask, fr, off, L, k, 0.5, algo, 1 if algo else 0)
+            assert (kept1 == kept).all() and (root1 == root).all(), name
+            assert st["n_edges"] == st1["n_edges"], name
     finally:
         c.close()
 
