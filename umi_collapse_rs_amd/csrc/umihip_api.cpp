@@ -657,7 +657,7 @@ class Pipeline {
         std::vector<uint32_t> pos;
         pos.reserve(n_pos);
         for (auto &bb : pl.bs_buckets) {
-            HIP_TRY(sort_bucket(ctx->fkey.p, key32, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+            HIP_TRY(sort_bucket(ctx->fkey.p, key32, 0, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                 ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                 ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
             for (uint64_t q = bb.s; q < bb.e; q += BS_COL_TILE) pos.push_back((uint32_t)q);
@@ -706,10 +706,16 @@ class Pipeline {
             HIP_TRY(launch_iota(ctx->perm.as<uint32_t>(), n, s));
         }
         for (auto &bb : pl.bs_buckets)
-            if (bb.pu || bb.live)
-                HIP_TRY(sort_bucket(ctx->fkey.p, key32, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
+            if (bb.pu || bb.live) {
+                // The scan + item walk never look at the order inside a column run: the two live
+                // units (8 bits) can stay unsorted, one radix pass less.  Only on the onesweep
+                // path (>= 65536 entries; the library's merge path below that aborted with a
+                // restricted bit range on this box).
+                const int begin_bit = bb.live && bb.e - bb.s >= 65536 ? 4 * bb.live : 0;
+                HIP_TRY(sort_bucket(ctx->fkey.p, key32, begin_bit, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                     ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                     ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
+            }
         bs_fkey = ctx->fkey_sorted.p;
         bs_perm = ctx->perm.as<uint32_t>();
         return UMI_OK;

@@ -149,7 +149,8 @@ hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries,
 size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits);
 // fkey_sorted[start..start+n) = sorted keys, perm[start + i] = original global index of the
 // i-th smallest; iota_tmp is scratch of the same extent
-hipError_t sort_bucket(const void *fkey, bool key32, int key_bits, uint32_t start, uint32_t n, void *fkey_sorted,
+// (by the bits [begin_bit, key_bits) of the key only)
+hipError_t sort_bucket(const void *fkey, bool key32, int begin_bit, int key_bits, uint32_t start, uint32_t n, void *fkey_sorted,
                        uint32_t *perm, uint32_t *iota_tmp, void *tmp, size_t tmp_bytes,
                        hipStream_t s);
 // out[i] = keys[pos[i]] widened to 64 bits

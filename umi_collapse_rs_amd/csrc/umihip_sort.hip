@@ -51,7 +51,7 @@ size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits)
     return bytes;
 }
 
-hipError_t sort_bucket(const void *fkey, bool key32, int key_bits, uint32_t start, uint32_t n,
+hipError_t sort_bucket(const void *fkey, bool key32, int begin_bit, int key_bits, uint32_t start, uint32_t n,
                        void *fkey_sorted, uint32_t *perm, uint32_t *iota_tmp, void *tmp,
                        size_t tmp_bytes, hipStream_t s)
 {
@@ -61,10 +61,10 @@ hipError_t sort_bucket(const void *fkey, bool key32, int key_bits, uint32_t star
     if (key32)
         return rocprim::radix_sort_pairs<sort_config>(tmp, tmp_bytes, (const uint32_t *)fkey + start,
                                                       (uint32_t *)fkey_sorted + start, iota_tmp + start,
-                                                      perm + start, n, 0, key_bits, s);
+                                                      perm + start, n, begin_bit, key_bits, s);
     return rocprim::radix_sort_pairs<sort_config>(tmp, tmp_bytes, (const uint64_t *)fkey + start,
                                                   (uint64_t *)fkey_sorted + start, iota_tmp + start,
-                                                  perm + start, n, 0, key_bits, s);
+                                                  perm + start, n, begin_bit, key_bits, s);
 }
 
 hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32_t n, uint64_t *out,
