@@ -26,9 +26,9 @@ if ROOT not in sys.path:
 # (MI355X_MICROARCH.md: SIMD-32, 2.4 GHz max clock; = half the 157.3 TFLOP/s FP32 FMA peak)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_CONFIG2 = (394627.0 + 5263.9 + 8881.9 + 1243.5) * 1024  # bytes per launch of bs_run_kernel +
-# tab_scan_kernel at config 2: FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v11.csv
-# wave instructions per bs_run_kernel launch at config 2 (profiles/r01_config2_sq_counters_v11.csv):
+TRAFFIC_CONFIG2 = (395077.5 + 5265.0 + 8881.2 + 1243.1) * 1024  # bytes per launch of bs_run_kernel +
+# tab_scan_kernel at config 2: FETCH_SIZE + WRITE_SIZE (KB) of profiles/r01_config2_pmc_fetch_write_v12.csv
+# wave instructions per bs_run_kernel launch at config 2 (profiles/r01_config2_sq_counters_v12.csv):
 VALU_INSTS_CONFIG2 = 1.606e8
 INSTS_CONFIG2 = 1.606e8 + 0.917e8 + 0.324e8 + 0.077e8 + 0.022e8  # + scalar, branch, LDS, VMEM
 ISSUE_PEAK = 256 * 4 * 2.4e9  # one instruction per SIMD and clock
