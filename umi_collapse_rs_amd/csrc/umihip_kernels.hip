@@ -2189,7 +2189,21 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
 // A single word takes ~90 atomics per microsecond, and hooks pile up on the roots of the big
 // trees: the lanes that share the first pending lane's target send one atomic for their
 // minimum, twice; what is left goes one by one.
-__device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uint32_t val, bool todo)
+// A wave keeps the minimum for its hottest target (the leader target of its last trip: the root of
+// the giant component for most of them) in registers across the trips of its loop and sends it
+// once, when the target changes or the kernel ends.
+struct HotMin {
+    uint32_t t = 0xFFFFFFFFu, m = 0xFFFFFFFFu; // (wave-uniform)
+};
+__device__ __forceinline__ void hot_flush(uint32_t *arr, HotMin &h)
+{
+    // (a fresh look first: while this wave gathered, others have usually lowered the word)
+    if (h.t != 0xFFFFFFFFu && (threadIdx.x & 63) == 0 && __atomic_load_n(&arr[h.t], __ATOMIC_RELAXED) > h.m)
+        atomicMin(&arr[h.t], h.m);
+    h.t = 0xFFFFFFFFu;
+    h.m = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uint32_t val, bool todo, HotMin &h)
 {
     for (int pass = 0; pass < 2 && __any(todo); pass++) {
         const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
@@ -2198,9 +2212,15 @@ __device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uin
         uint32_t m = mine ? val : 0xFFFFFFFFu;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
-        // (a fresh look first: while this wave gathered, others have usually lowered the word)
-        if ((int)(threadIdx.x & 63) == leader && __atomic_load_n(&arr[tgt], __ATOMIC_RELAXED) > m)
+        if (tgt == h.t) {
+            h.m = min(h.m, m);
+        } else if (pass == 0) { // the new hot target
+            hot_flush(arr, h);
+            h.t = tgt;
+            h.m = m;
+        } else if ((int)(threadIdx.x & 63) == leader && __atomic_load_n(&arr[tgt], __ATOMIC_RELAXED) > m) {
             atomicMin(&arr[tgt], m);
+        }
         todo = todo && !mine;
     }
     if (todo) atomicMin(&arr[idx], val);
@@ -2215,6 +2235,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ 
     unsigned long long ne = counters[CNT_EDGES];
     const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
     bool any = false;
+    HotMin hot;
     constexpr int ILP = 4;
     const uint32_t nth = gridDim.x * blockDim.x;
     for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < E; b0 += ILP * nth) { // (wave-uniform trip count)
@@ -2244,10 +2265,11 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ 
             const uint32_t lo = min(gu[i], gv[i]); // a member of the set, <= everything below
             // the parent with the larger grandparent: one target per pair, often a shared root
             const bool hook_u = live && lo < gu[i];
-            wave_atomic_min(comp, hook_u ? fu[i] : fv[i], lo, live && (lo < gu[i] || lo < gv[i]));
+            wave_atomic_min(comp, hook_u ? fu[i] : fv[i], lo, live && (lo < gu[i] || lo < gv[i]), hot);
             any |= live; // parents differ: one of them moved, or will once the jump has run
         }
     }
+    hot_flush(comp, hot);
     if (any) changed[round] = 1;
 }
 
@@ -2261,6 +2283,7 @@ __global__ __launch_bounds__(256) void dag_hook_kernel(const uint2 *__restrict__
     unsigned long long ne = counters[CNT_EDGES];
     const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
     bool any = false;
+    HotMin hot;
     // (every lane of a wave makes the same number of trips: the shuffles below need them all)
     for (uint32_t e0 = blockIdx.x * blockDim.x; e0 < E; e0 += gridDim.x * blockDim.x) {
         const uint32_t e = e0 + threadIdx.x;
@@ -2274,8 +2297,9 @@ __global__ __launch_bounds__(256) void dag_hook_kernel(const uint2 *__restrict__
             todo = lu < lab[cv];
         }
         any |= todo;
-        wave_atomic_min(lab, cv, lu, todo); // many one-way pairs point into the giant component
+        wave_atomic_min(lab, cv, lu, todo, hot); // many one-way pairs point into the giant component
     }
+    hot_flush(lab, hot);
     if (any) changed[round] = 1;
 }
 
@@ -2598,7 +2622,7 @@ hipError_t launch_dag_round(const uint2 *edges, const unsigned long long *counte
                             const uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t *changed,
                             int round, uint32_t n_edges_hint, hipStream_t s)
 {
-    dag_hook_kernel<<<grid_for(n_edges_hint, 256), 256, 0, s>>>(edges, counters, edge_cap, comp, lab,
+    dag_hook_kernel<<<grid_for(n_edges_hint, 256, 512), 256, 0, s>>>(edges, counters, edge_cap, comp, lab,
                                                                 changed, round);
     jump_kernel<<<grid_for(n, 256), 256, 0, s>>>(lab, n, changed, round);
     return hipGetLastError();
