@@ -302,6 +302,8 @@ def test_table_kernel_forced_on_several_buckets(L, k, algo):
     c = umi.Context(0)
     try:
         c.set_option("bs_tab_min_run", 0)
+        c.set_option("edge_capacity", 64)  # both lists run over on the first attempt: the pair
+        c.set_option("ovf_capacity", 16)   # stage is redone, scan and item counters included
         st = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=1 if algo else 0)
         assert st["n_pairs_evaluated"] > 0
         nmask = nm if nm.any() else None
