@@ -52,7 +52,8 @@ typedef struct umi_stats {
     uint64_t max_bucket;        /* max_umi_count of deduplicate_sam.rs:218 */
     uint64_t n_kept;            /* deduped_count of deduplicate_sam.rs:219 */
     uint64_t n_pairs;           /* W */
-    uint64_t n_pairs_evaluated; /* pairs the filter loop covered (tile padding included) */
+    uint64_t n_pairs_evaluated; /* pairs the filter kernels walked (tile padding included; key-sorted
+                                 * buckets: only the column tiles their scan kept, see bs_tables) */
     uint64_t n_candidates;      /* filter hits sent to the exact check */
     uint64_t n_edges;           /* directed edges fed to the collapse */
     uint32_t n_rounds;          /* label-propagation rounds */
