@@ -872,6 +872,8 @@ class Pipeline {
         }
         drained = true;
         if (prof) {
+            // (the pair stage records its end marker after its last synchronisation)
+            HIP_TRY(hipEventSynchronize(ctx->ev[2]));
             HIP_TRY(hipEventElapsedTime(&st.ms_prep, ctx->ev[0], ctx->ev[1]));
             HIP_TRY(hipEventElapsedTime(&st.ms_pairs, ctx->ev[1], ctx->ev[2]));
             st.ms_total = st.ms_prep + st.ms_pairs;
