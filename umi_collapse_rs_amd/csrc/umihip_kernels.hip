@@ -1520,12 +1520,13 @@ __global__ __launch_bounds__(64, 5) void bs_run_kernel(PairArgs a, const TabRowT
                     for (unsigned long long todo = open_lanes; todo;) {
                         const int la = __builtin_ctzll(todo);
                         todo &= todo - 1;
+                        uint32_t pl[LW]; // the open lane's live-unit planes, on the scalar side (all reads
+#pragma unroll                           // first: each one's use would otherwise wait out its hazard)
+                        for (int b = 0; b < LW; b++) pl[b] = (uint32_t)__builtin_amdgcn_readlane(lp[b], la);
                         auto unit = [&](int u) { // rows of lane la whose live unit u differs from this column's
-                            uint32_t m = (uint32_t)__builtin_amdgcn_readlane(lp[4 * u], la) ^ cm[4 * u];
+                            uint32_t m = pl[4 * u] ^ cm[4 * u];
 #pragma unroll
-                            for (int b = 1; b < 4; b++)
-                                m = BITOP3(m, (uint32_t)__builtin_amdgcn_readlane(lp[4 * u + b], la), cm[4 * u + b],
-                                           TT_A | (TT_B ^ TT_C));
+                            for (int b = 1; b < 4; b++) m = BITOP3(m, pl[4 * u + b], cm[4 * u + b], TT_A | (TT_B ^ TT_C));
                             return m;
                         };
                         uint32_t hg;
