@@ -137,6 +137,8 @@ def main():
     ap.add_argument("-p", type=float, default=0.5)
     ap.add_argument("--cpu-sample", type=int, default=80_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed block (profiling runs): no host-buffer call, no CPU baseline")
     ap.add_argument("--opt", action="append", default=[], help="ctx option name=value (tuning)")
     ap.add_argument("--split", action="store_true",
                     help="N>1 only: strong scaling -- ONE giant position, its tile tasks split over "
@@ -268,7 +270,7 @@ def main():
     # the same pass through the host-buffer entry point (H2D of keys/freq + D2H of the mask
     # inside the call): the PCIe-inclusive rate, reported beside `value`, never as it
     host_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         ctx.dedup_batch(st["keys"], None, st["freq"], boff, args.umi_len, k=args.k,
                         percentage=args.p, want_root=False)
         t1 = time.perf_counter()
@@ -370,7 +372,7 @@ def main():
             "counters": {"n_edges": s0["n_edges"], "n_candidates": s0["n_candidates"],
                          "n_rounds": s0["n_rounds"], "pairs_evaluated": s0["n_pairs_evaluated"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(st, args.cpu_sample, args.k, args.p, args.umi_len,
                                                args.config)
         print(json.dumps(out))

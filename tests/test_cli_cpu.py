@@ -110,3 +110,60 @@ def test_cli_error_behaviour(tmp_path):
     write_bam(src, header, bad)
     r = run(["-i", src, "-o", dst, "--dump-staging", str(tmp_path / "s.bin")])
     assert r.returncode != 0 and "Unknown character" in r.stderr
+
+
+def _expect_clean_failure(args):
+    """A malformed file ends the program with its own error message and a non-zero status --
+    never a signal (the reference fails with 'Failed to parse record' through htslib)."""
+    r = run(args)
+    assert r.returncode > 0, "rc=%d stderr=%s" % (r.returncode, r.stderr[-300:])
+    assert r.stderr.strip() != ""
+    return r
+
+
+def test_truncated_and_corrupt_inputs_fail_cleanly(tmp_path):
+    header, recs = bamio.synthetic_bam(5, 20, 20, extras=False)
+    stream = header + b"".join(recs)
+    src, dst = str(tmp_path / "bad.bam"), str(tmp_path / "o.bam")
+    good = bamio.bgzf_compress(stream)
+    cases = {}
+    # BGZF level
+    cases["cut_in_header"] = good[:11]
+    cases["cut_in_block"] = good[:len(good) // 2]
+    cases["xlen_past_file"] = good[:10] + b"\xff\xff" + good[12:40]
+    bsz = bytearray(good); bsz[16:18] = (5).to_bytes(2, "little")  # BSIZE smaller than header + trailer
+    cases["bsize_too_small"] = bytes(bsz)
+    first_len = int.from_bytes(good[16:18], "little") + 1
+    isz = bytearray(good); isz[first_len - 4:first_len] = (0x7fffffff).to_bytes(4, "little")
+    cases["isize_huge"] = bytes(isz)
+    crp = bytearray(good); crp[30] ^= 0xff; crp[31] ^= 0x55
+    cases["deflate_payload_corrupt"] = bytes(crp)
+    # BAM level (well-formed BGZF around a malformed stream)
+    def bam(b):
+        return bamio.bgzf_compress(bytes(b))
+    cases["bam_cut_mid_record"] = bam(stream[:len(header) + len(recs[0]) + 17])
+    neg = bytearray(stream); neg[4:8] = (-5).to_bytes(4, "little", signed=True)
+    cases["negative_l_text"] = bam(neg)
+    big = bytearray(stream); big[4:8] = (1 << 30).to_bytes(4, "little")
+    cases["l_text_past_end"] = bam(big)
+    l_text = int.from_bytes(stream[4:8], "little")
+    nref = bytearray(stream); nref[8 + l_text:12 + l_text] = (-1).to_bytes(4, "little", signed=True)
+    cases["negative_n_ref"] = bam(nref)
+    lname = bytearray(stream); lname[12 + l_text:16 + l_text] = (0x7ffffff0).to_bytes(4, "little")
+    cases["l_name_past_end"] = bam(lname)
+    r0 = len(header)
+    lseq = bytearray(stream); lseq[r0 + 4 + 16:r0 + 4 + 20] = (100000).to_bytes(4, "little")
+    cases["l_seq_past_record"] = bam(lseq)
+    lneg = bytearray(stream); lneg[r0 + 4 + 16:r0 + 4 + 20] = (-3).to_bytes(4, "little", signed=True)
+    cases["negative_l_seq"] = bam(lneg)
+    ncig = bytearray(stream); ncig[r0 + 4 + 12:r0 + 4 + 14] = (0xffff).to_bytes(2, "little")
+    cases["n_cigar_past_record"] = bam(ncig)
+    bsneg = bytearray(stream); bsneg[r0:r0 + 4] = (-1).to_bytes(4, "little", signed=True)
+    cases["negative_block_size"] = bam(bsneg)
+    cases["not_bam_magic"] = bam(b"BAX\x01" + stream[4:])
+    for name, blob in cases.items():
+        with open(src, "wb") as f:
+            f.write(blob)
+        for extra in (["--passthrough"], ["--dump-staging", str(tmp_path / "s.bin")]):
+            r = _expect_clean_failure(["-i", src, "-o", dst] + extra)
+            assert "Segmentation" not in r.stderr, name

@@ -284,6 +284,36 @@ def test_wide_sorted_buckets(L, k, n_raw, n_frac, algo, amf):
         c.close()
 
 
+@pytest.mark.parametrize("n_extra", [0, 1])
+def test_bucket_at_the_sort_merge_boundary(n_extra):
+    """A saturated 8-bp position holds all 4^8 = 65536 UMIs: exactly the size up to which the
+    library sort takes its merge path (size <= merge_sort_limit); one entry more goes through the
+    onesweep passes with the restricted bit range.  Both against the oracle, and with the scan +
+    walk forced (bs_tab_min_run = 0) so that the key-sorted path is the one that runs."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(4 ** 8 + n_extra)
+    L = 8 + n_extra
+    ids = np.arange(4 ** 8, dtype=np.int64)
+    if n_extra:  # 9-mers: every 8-mer with a fixed ninth base, and one more
+        ids = np.concatenate([ids, [4 ** 8 + 12345]])
+    umis = ["".join("ACGT"[(int(i) >> (2 * b)) & 3] for b in range(L)) for i in ids]
+    rng.shuffle(umis)
+    freq = np.minimum(rng.geometric(0.5, len(umis)), 30).tolist()
+    umis, freq, _ = canonical(umis, freq)
+    keys, nm = orc.encode_keys(umis)
+    fr, off = np.array(freq, np.int32), np.array([0, len(umis)], np.uint64)
+    assert len(keys) == 65536 + n_extra
+    c = umi.Context(0)
+    try:
+        c.set_option("bs_tab_min_run", 0)
+        st = check_against_oracle(c, keys, nm, fr, off, L, 1)
+        c.set_option("bs_sorted", 0)
+        st0 = check_against_oracle(c, keys, nm, fr, off, L, 1)
+        assert st["n_edges"] == st0["n_edges"]
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("L,k,algo", [(12, 1, 0), (13, 2, 0), (16, 3, 0), (11, 0, 0), (12, 1, 1)])
 def test_table_kernel_forced_on_several_buckets(L, k, algo):
     """bs_tab_min_run = 0 sends every bucket of >= 32768 entries with 32-bit keys through the scan +

@@ -709,9 +709,8 @@ class Pipeline {
             if (bb.pu || bb.live) {
                 // The scan + item walk never look at the order inside a column run: the two live
                 // units (8 bits) can stay unsorted, one radix pass less.  Only on the onesweep
-                // path (>= 65536 entries; the library's merge path below that aborted with a
-                // restricted bit range on this box).
-                const int begin_bit = bb.live && bb.e - bb.s >= 65536 ? 4 * bb.live : 0;
+                // path (the library's merge path for smaller inputs gets the full key).
+                const int begin_bit = bb.live && sort_is_onesweep((uint32_t)(bb.e - bb.s)) ? 4 * bb.live : 0;
                 HIP_TRY(sort_bucket(ctx->fkey.p, key32, begin_bit, key_bits(), (uint32_t)bb.s, (uint32_t)(bb.e - bb.s),
                                     ctx->fkey_sorted.p, ctx->perm.as<uint32_t>(),
                                     ctx->iota.as<uint32_t>(), ctx->sort_tmp.p, tmp_bytes, s));
@@ -1317,6 +1316,8 @@ int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, cons
     if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
         return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
     if (max_edits < 0) return fail(UMI_ERR_ARG, "max_edits must be >= 0");
+    if (n >= 0x7FFFFFF0u) // same index space as the batched calls (bit 31 of an edge endpoint is a flag)
+        return fail(UMI_ERR_ARG, "%u entries exceed the 31-bit index space of one store", n);
     std::unique_ptr<umi_data> d(new (std::nothrow) umi_data());
     if (!d) return fail(UMI_ERR_NOMEM, "out of host memory");
     d->ctx = ctx;

@@ -147,6 +147,9 @@ hipError_t launch_verify_list(const PairArgs &a, bool key32, uint32_t n_entries,
 
 // ---- optional prune mode (umihip_sort.hip): sort a large bucket's entries by filter key
 size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits);
+// true if a bucket of n entries goes through the library's onesweep passes (a restricted bit
+// range is only handed to those; its merge path for smaller inputs gets the full key)
+bool sort_is_onesweep(uint32_t n);
 // fkey_sorted[start..start+n) = sorted keys, perm[start + i] = original global index of the
 // i-th smallest; iota_tmp is scratch of the same extent
 // (by the bits [begin_bit, key_bits) of the key only)

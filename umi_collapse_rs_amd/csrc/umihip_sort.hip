@@ -31,11 +31,16 @@ __global__ __launch_bounds__(256) void gather_kernel(const KeyT *__restrict__ ke
 }
 } // namespace
 
-// Onesweep radix passes from 65536 items up (the library's default switches to a block sort +
-// ten merge passes below 2^20 items: 0.16 ms for the 970,714 keys of BASELINE config 2), and
-// only over the bits a key of this UMI length can have.
+// Onesweep radix passes above SORT_MERGE_LIMIT items (the library's default switches to a block
+// sort + ten merge passes below 2^20 items: 0.16 ms for the 970,714 keys of BASELINE config 2),
+// and only over the bits a key of this UMI length can have.  rocPRIM takes its merge path for
+// size <= merge_sort_limit (device_radix_sort.hpp:644), i.e. a bucket of exactly
+// SORT_MERGE_LIMIT entries still merges.
+constexpr uint32_t SORT_MERGE_LIMIT = 65536;
 using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 65536>;
+                                               rocprim::default_config, SORT_MERGE_LIMIT>;
+
+bool sort_is_onesweep(uint32_t n) { return n > SORT_MERGE_LIMIT; }
 
 size_t sort_temp_bytes(bool key32, uint32_t n, int key_bits)
 {

@@ -116,28 +116,42 @@ struct File {
     int32_t n_ref = 0;
     std::vector<Record> records;
 
+    // Every length field of the file is checked against the bytes that are there before anything
+    // is indexed by it: a truncated or corrupt file ends in FormatError ("Failed to parse record",
+    // the message of the reference's htslib read loop, deduplicate_sam.rs:93-95), never in a read
+    // outside the buffer.
     void parse()
     {
-        const uint8_t *p = data.data(), *e = p + data.size();
-        if (data.size() < 12 || std::memcmp(p, "BAM\1", 4) != 0) throw FormatError("Invalid input path: not a BAM file");
+        const uint8_t *p = data.data();
+        const size_t size = data.size();
+        if (size < 12 || std::memcmp(p, "BAM\1", 4) != 0) throw FormatError("Invalid input path: not a BAM file");
         const int32_t l_text = rd_i32(p + 4);
-        const uint8_t *q = p + 8 + l_text;
-        if (q + 4 > e) throw FormatError("truncated BAM header");
-        n_ref = rd_i32(q);
+        if (l_text < 0 || (size_t)l_text > size - 12) throw FormatError("truncated BAM header");
+        size_t q = 8 + (size_t)l_text; // offsets, not pointers: nothing is formed past the buffer
+        n_ref = rd_i32(p + q);
         q += 4;
+        if (n_ref < 0 || (size_t)n_ref > (size - q) / 8) throw FormatError("truncated BAM header");
         for (int32_t r = 0; r < n_ref; r++) {
-            if (q + 4 > e) throw FormatError("truncated BAM header");
-            const int32_t l_name = rd_i32(q);
-            q += 4 + l_name + 4;
+            if (size - q < 4) throw FormatError("truncated BAM header");
+            const int32_t l_name = rd_i32(p + q);
+            q += 4;
+            if (l_name < 0 || size - q < 4 || (size_t)l_name > size - q - 4) throw FormatError("truncated BAM header");
+            q += (size_t)l_name + 4;
         }
-        if (q > e) throw FormatError("truncated BAM header");
-        header_len = (size_t)(q - p);
-        while (q < e) {
-            if (q + 4 > e) throw FormatError("Failed to parse record");
-            const int32_t bs = rd_i32(q);
-            if (bs < 32 || q + 4 + bs > e) throw FormatError("Failed to parse record");
-            records.push_back({q, q + 4 + bs});
-            q += 4 + bs;
+        header_len = q;
+        while (q < size) {
+            if (size - q < 4) throw FormatError("Failed to parse record");
+            const int32_t bs = rd_i32(p + q);
+            if (bs < 32 || (size_t)bs > size - q - 4) throw FormatError("Failed to parse record");
+            const Record rec{p + q, p + q + 4 + (size_t)bs};
+            // the variable-length fields must fit the record: qname, cigar, packed seq, qual
+            const int32_t l_seq = rec.l_seq();
+            if (l_seq < 0) throw FormatError("Failed to parse record");
+            const uint64_t need = 32ull + rec.l_read_name() + 4ull * rec.n_cigar() +
+                                  ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+            if (need > (uint64_t)bs) throw FormatError("Failed to parse record");
+            records.push_back(rec);
+            q += 4 + (size_t)bs;
         }
     }
 };

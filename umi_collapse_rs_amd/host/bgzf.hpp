@@ -80,16 +80,24 @@ inline std::vector<uint8_t> decompress(const std::vector<uint8_t> &in, unsigned 
         if (in.size() - off < 18 || in[off] != 0x1f || in[off + 1] != 0x8b || in[off + 2] != 8 || !(in[off + 3] & 4))
             throw IoError("not a BGZF block at offset " + std::to_string(off));
         const uint32_t xlen = in[off + 10] | (in[off + 11] << 8);
-        size_t x = off + 12, xend = x + xlen;
+        size_t x = off + 12;
+        const size_t xend = x + xlen;
+        if (xend > in.size()) throw IoError("truncated BGZF block");
         uint32_t bsize = 0;
         while (x + 4 <= xend) {
             const uint32_t slen = in[x + 2] | (in[x + 3] << 8);
-            if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2) bsize = (in[x + 4] | (in[x + 5] << 8)) + 1u;
-            x += 4 + slen;
+            if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= xend)
+                bsize = (in[x + 4] | (in[x + 5] << 8)) + 1u;
+            x += 4 + (size_t)slen;
         }
-        if (!bsize || off + bsize > in.size()) throw IoError("truncated BGZF block");
+        // a block holds its header, the extra field and the 8-byte trailer (CRC32, ISIZE) at least
+        if (!bsize || bsize > in.size() - off || (size_t)bsize < (xend - off) + 8)
+            throw IoError("truncated BGZF block");
         const size_t tail = off + bsize - 8;
         const uint32_t isize = in[tail + 4] | (in[tail + 5] << 8) | (in[tail + 6] << 16) | ((uint32_t)in[tail + 7] << 24);
+        // (a BGZF block inflates to at most 64 KiB; a larger ISIZE is a corrupt trailer, and the
+        // sum would size the output buffer)
+        if (isize > 0x10000u) throw IoError("Failed to parse record: corrupt BGZF block");
         blocks.push_back({xend, (uint32_t)(tail - xend), isize, total});
         total += isize;
         off += bsize;
