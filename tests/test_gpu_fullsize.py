@@ -80,9 +80,11 @@ def test_config2_one_million_reads_single_position(ctx):
     assert kept0.all() and (root0 == np.arange(len(keys))).all()
     kept_adj, _, _ = ctx.dedup_batch(keys, None, freq, off, 12, k=1, algo=1)
     assert kept_adj.all()
-    # the popcount tile kernel on the same input gives the same answer as the bit-sliced one
+    # the true all-pairs popcount tile kernel on the same input (every one of the W pairs is
+    # evaluated) gives the same answer as the segment index
     import umi_collapse_rs_amd as umi
     c2 = umi.Context(0)
+    c2.set_option("seg_index", 0)
     c2.set_option("bitslice", 0)
     try:
         kept2, root2, _ = c2.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
@@ -98,8 +100,19 @@ def test_config2_one_million_reads_single_position(ctx):
         c3.close()
     assert (kept3 == kept).all() and (root3 == root).all()
     assert st3["n_pairs_evaluated"] < stats["n_pairs"] // 2
-    # the default path walks only the column tiles whose high bases leave a row within k
-    assert stats["n_pairs_evaluated"] < stats["n_pairs"] // 3
+    # the key-sorted scan + walk of the earlier versions: only the column tiles whose high bases
+    # leave a row within k
+    c4 = umi.Context(0)
+    c4.set_option("seg_index", 0)
+    try:
+        kept4, root4, st4 = c4.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    finally:
+        c4.close()
+    assert (kept4 == kept).all() and (root4 == root).all() and st4["n_edges"] == stats["n_edges"]
+    assert st4["n_pairs_evaluated"] < stats["n_pairs"] // 3
+    # the default path evaluates the pairs inside the sub-buckets of its two 6-base parts:
+    # 2 x 4096 sub-buckets of ~237 entries
+    assert stats["n_pairs_evaluated"] < stats["n_pairs"] // 1000
 
 
 @pytest.mark.parametrize("L,k,n_reads", [(13, 1, 1_300_000), (12, 2, 600_000), (11, 0, 500_000)])
@@ -113,7 +126,8 @@ def test_table_kernel_against_the_other_tile_kernels(L, k, n_reads):
     st = synth.config2(seed=40 + L, n_reads=n_reads, umi_len=L)
     keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
     outs = []
-    for opts in ({}, {"bs_transposed": 0}, {"bs_tables": 0}, {"bs_sorted": 0}):
+    for opts in ({}, {"seg_index": 0}, {"seg_index": 0, "bs_transposed": 0}, {"seg_index": 0, "bs_tables": 0},
+                 {"seg_index": 0, "bs_sorted": 0}):
         c = umi.Context(0)
         try:
             for name, v in opts.items():

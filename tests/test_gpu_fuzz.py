@@ -53,7 +53,8 @@ def test_fuzz_against_oracle(seed):
     keys, nm = np.concatenate(keys), np.concatenate(nm)
     fr, off = np.array(fr, np.int32), np.array(off, np.uint64)
     okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
-    for opts in ({}, {"prune": 1}, {"bitslice": 0, "fused_max": 0}, {"bs_unit": 1, "small_max": 200}):
+    for opts in ({}, {"prune": 1}, {"bitslice": 0, "fused_max": 0}, {"bs_unit": 1, "small_max": 200, "seg_index": 0},
+                 {"seg_index": 0}, {"seg_min": 129, "two_phase": 1}):
         ctx = umi.Context(0)
         try:
             for name, v in opts.items():
@@ -87,7 +88,7 @@ def test_fuzz_wide_buckets(seed):
     keys, nm = np.concatenate(keys), np.concatenate(nm)
     fr, off = np.array(fr, np.int32), np.array(off, np.uint64)
     okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
-    for opts in ({}, {"bs_tables": 0}, {"prune": 1}):
+    for opts in ({}, {"seg_index": 0}, {"seg_index": 0, "bs_tables": 0}, {"prune": 1}, {"two_phase": 1}):
         ctx = umi.Context(0)
         try:
             for name, v in opts.items():

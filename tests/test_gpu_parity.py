@@ -8,10 +8,15 @@ from helpers import canonical, random_bucket
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["default", "nofuse", "prune", "fused_walk", "label_prop"])
+@pytest.fixture(scope="module", params=["default", "nofuse", "prune", "fused_walk", "label_prop", "tiles",
+                                        "hook_rounds", "seg_small"])
 def ctx(request):
-    """default: fused one-wave kernel for buckets <= 128, popcount chunks to 1024, bit-sliced
-    tiles above.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list.
+    """default: fused one-wave kernel for buckets <= 128, popcount chunks to the segment index's
+    lower bound (512), the n-gram partition (segment index) above, union-find collapse, one host
+    synchronisation.  nofuse: buckets <= 1024 all go through the chunk kernel + edge list.
+    tiles: no segment index -- popcount chunks to 1024, bit-sliced tiles above (the kernels of the
+    earlier versions).  hook_rounds: the symmetric components by hook/jump rounds instead of
+    union-find.  seg_small: the segment index from 130 entries up, no fused kernel.
     prune: every bucket > 128 through key-sorted bit-sliced tiles with range pruning.
     fused_walk: the fused kernel's column-walking body instead of its bit-sliced one.
     label_prop: no fused kernel, and plain label propagation instead of the two-phase collapse."""
@@ -27,6 +32,13 @@ def ctx(request):
     if request.param == "prune":
         c.set_option("prune", 1)
         c.set_option("small_max", 128)
+    if request.param == "tiles":
+        c.set_option("seg_index", 0)
+    if request.param == "hook_rounds":
+        c.set_option("two_phase", 1)
+    if request.param == "seg_small":
+        c.set_option("seg_min", 130)
+        c.set_option("fused_max", 0)
     yield c
     c.close()
 
@@ -169,6 +181,7 @@ def test_tile_kernels_on_all_sizes(bitslice, unit):
     c = umi.Context(0)
     c.set_option("small_max", 0)
     c.set_option("fused_max", 0)
+    c.set_option("seg_index", 0)
     c.set_option("bitslice", bitslice)
     c.set_option("bs_unit", unit)
     try:
@@ -209,8 +222,11 @@ def test_bitsliced_rows_beyond_one_tile_and_column_chunks():
     off = np.array([0, len(umis)], np.uint64)
     c = umi.Context(0)
     try:
+        st_seg = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
+        c.set_option("seg_index", 0)  # the bit-sliced tiles
         st = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
-        assert st["n_pair_launches"] >= 1
+        assert st["n_pair_launches"] >= 1 and st["n_edges"] == st_seg["n_edges"]
+        assert st_seg["n_pairs_evaluated"] < st["n_pairs"] < st["n_pairs_evaluated"]
         c.set_option("prune", 1)
         st2 = check_against_oracle(c, keys, nm, np.array(freq, np.int32), off, L, 1)
         assert st2["n_pairs_evaluated"] <= st["n_pairs_evaluated"]  # tile tasks may be skipped
@@ -274,7 +290,10 @@ def test_wide_sorted_buckets(L, k, n_raw, n_frac, algo, amf):
     assert len(keys) >= 32768
     c = umi.Context(0)
     try:
+        st_seg = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
+        c.set_option("seg_index", 0)
         st = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
+        assert st_seg["n_edges"] == st["n_edges"]
         c.set_option("bs_tables", 0)
         st1 = check_against_oracle(c, keys, nm, fr, off, L, k, algo=algo, amf=amf)
         c.set_option("bs_sorted", 0)
@@ -305,11 +324,13 @@ def test_bucket_at_the_sort_merge_boundary(n_extra):
     assert len(keys) == 65536 + n_extra
     c = umi.Context(0)
     try:
+        st_seg = check_against_oracle(c, keys, nm, fr, off, L, 1)
+        c.set_option("seg_index", 0)
         c.set_option("bs_tab_min_run", 0)
         st = check_against_oracle(c, keys, nm, fr, off, L, 1)
         c.set_option("bs_sorted", 0)
         st0 = check_against_oracle(c, keys, nm, fr, off, L, 1)
-        assert st["n_edges"] == st0["n_edges"]
+        assert st["n_edges"] == st0["n_edges"] == st_seg["n_edges"]
     finally:
         c.close()
 
@@ -331,6 +352,7 @@ def test_table_kernel_forced_on_several_buckets(L, k, algo):
     off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint64)
     c = umi.Context(0)
     try:
+        c.set_option("seg_index", 0)
         c.set_option("bs_tab_min_run", 0)
         c.set_option("edge_capacity", 64)  # both lists run over on the first attempt: the pair
         c.set_option("ovf_capacity", 16)   # stage is redone, scan and item counters included
@@ -376,22 +398,27 @@ def test_wide_sorted_bucket_dense_in_neighbours(L, k):
     fr, off = np.array(freq, np.int32), np.array([0, len(umis)], np.uint64)
     c = umi.Context(0)
     try:
+        st_seg = check_against_oracle(c, keys, nm, fr, off, L, k)  # segment index: dense sub-buckets
+        assert st_seg["n_candidates"] >= st_seg["n_edges"] > (8 if k == 2 else 1) * len(umis)
+        c.set_option("seg_index", 0)
         st = check_against_oracle(c, keys, nm, fr, off, L, k)
         assert st["n_candidates"] > (8 if k == 2 else 1) * len(umis)
         c.set_option("bs_sorted", 0)
         st0 = check_against_oracle(c, keys, nm, fr, off, L, k)
-        assert st0["n_edges"] == st["n_edges"]
+        assert st0["n_edges"] == st["n_edges"] == st_seg["n_edges"]
     finally:
         c.close()
     # the global overflow list itself too short at first: everything again with a longer one
-    c = umi.Context(0)
-    c.set_option("ovf_capacity", 16)
-    c.set_option("edge_capacity", 64)
-    try:
-        st1 = check_against_oracle(c, keys, nm, fr, off, L, k)
-        assert st1["n_edges"] == st["n_edges"]
-    finally:
-        c.close()
+    for seg_index in (0, 1):
+        c = umi.Context(0)
+        c.set_option("seg_index", seg_index)
+        c.set_option("ovf_capacity", 16)
+        c.set_option("edge_capacity", 64)
+        try:
+            st1 = check_against_oracle(c, keys, nm, fr, off, L, k)
+            assert st1["n_edges"] == st["n_edges"]
+        finally:
+            c.close()
 
 
 def test_edge_list_overflow_is_transparent():

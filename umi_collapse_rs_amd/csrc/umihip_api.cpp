@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "umihip_internal.h"
+#include "umihip_plan.hpp"
 
 using namespace umihip;
 
@@ -71,48 +72,43 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
-struct Plan {
-    std::vector<PairTask> small_tasks, big_tasks;
-    // bit-sliced tasks: [0] column-split tiles, [1] wide tiles, [2]/[3] wide tiles of key-sorted
-    // buckets whose kernel keeps the counter state of the 3 / 4 highest units per column run
-    std::vector<BsTask> bs_tasks[4];
-    // table variant (key-sorted, 32-bit keys, 2 live units): row tiles; the column tiles to walk
-    // are found on the device (tab_items_max = all of them)
-    std::vector<TabRowTile> tab_rows;
-    uint64_t tab_items_max = 0;
-    uint64_t n_pairs_eval_tab = 0; // their share of n_pairs_eval if every column tile were walked
-    std::vector<PlaneTask> plane_tasks;
-    // entries of the buckets the fused kernel does not take, in chunks: what prep and finalize
-    // work on (empty for a batch of small positions)
-    std::vector<RangeTask> ranges;
-    struct BsBucket {
-        uint64_t s, e, plane_off;
-        uint32_t ngroups;
-        bool wide;
-        int pu;   // prefix units cached per column run (0: none; needs the bucket sorted by key)
-        int live; // table variant: units looked up per column (0: not the table variant)
-    };
-    std::vector<BsBucket> bs_buckets;
-    uint64_t n_fused = 0; // buckets left to the fused one-wave kernel
-    uint64_t plane_words = 0;
-    uint64_t n_pairs = 0, n_pairs_eval = 0, max_bucket = 0, n_tasks_pruned = 0;
-    size_t n_bs() const
+constexpr int MAX_ROUNDS = 1 << 20;
+constexpr int DAG_ROUNDS = 3; // one-way rounds enqueued before the host first looks (freq at least
+                              // halves along a one-way pair at p <= 0.5: depth 2 at config 2)
+
+// grow-only pinned host buffer; every write goes through put(), which checks the extent
+struct PinnedBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
     {
-        size_t t = 0;
-        for (auto &v : bs_tasks) t += v.size();
-        return t;
+        if (bytes <= cap) return UMI_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc((void **)&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(UMI_ERR_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return UMI_OK;
     }
-    bool any_sorted() const
+    int put(size_t off, const void *src, size_t bytes)
     {
-        for (auto &bb : bs_buckets)
-            if (bb.pu || bb.live) return true;
-        return false;
+        if (off > cap || bytes > cap - off)
+            return fail(UMI_ERR_HIP, "internal: staging write of %zu bytes at %zu beyond %zu", bytes, off, cap);
+        if (bytes) memcpy(p + off, src, bytes);
+        return UMI_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
     }
 };
-
-constexpr int MAX_ROUNDS_PER_SYNC = 16; // rounds enqueued between two host checks (4, 8, 16, 16, ...)
-constexpr int MAX_ROUNDS = 1 << 20;
-constexpr uint32_t BIG_COL_CHUNK = 16 * COL_TILE; // columns per big task
 
 } // namespace
 
@@ -134,10 +130,18 @@ struct umi_ctx {
     int bs_unit = 2;
     bool bs_sorted = true; // sort large buckets by key and reuse prefix state along column runs
     bool bs_tables = true; // ... and look the low units up in per-lane register tables (32-bit keys)
-    bool two_phase = true; // directional collapse: components of the symmetric pairs, then the DAG
+    int two_phase = 2; // directional collapse: 0 plain label propagation; 1 components of the symmetric
+                       // pairs by hook/jump rounds, then the DAG; 2 the components by union-find
+    bool seg_index = true;   // large buckets through the n-gram partition (umihip_seg.hip)
+    uint32_t seg_min = 512;  // ... from this many entries up
+    uint32_t seg_dbg = 0;
+    uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: 24 per CU, all resident at once)
     // workspace
-    DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, tasks, counters, changed, boff, status, blocked;
-    DevBuf bs_tasks, plane_tasks, planes, ranges, tab_rows, tab_items;
+    DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, counters, boff, status, blocked;
+    DevBuf plan_tables; // ranges, segment descriptors, scan chunks, popcount tile tasks: one upload
+    DevBuf bs_tasks, plane_tasks, planes, tab_rows, tab_items;
+    DevBuf seg_bin_cnt, seg_bin_start, seg_chunk_sums, seg_tasks, seg_sub_rec, seg_priv_edges, seg_priv_dist, seg_priv_cnt;
+    PinnedBuf h_plan;
     int n_cus = 256;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
@@ -146,192 +150,14 @@ struct umi_ctx {
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
     uint64_t *h_boff = nullptr;               // pinned staging of the bucket table
     size_t h_boff_cap = 0;
-    void *h_tasks = nullptr;                  // pinned staging of the tile-task lists
-    size_t h_tasks_cap = 0;
-    unsigned long long *h_counters = nullptr; // pinned
-    uint32_t *h_changed = nullptr;            // pinned
+    PinnedBuf h_tasks;                        // pinned staging of the bit-sliced tile-task lists
+    unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES)
+    uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
+    uint32_t *d_changed() const { return (uint32_t *)(counters.as<unsigned long long>() + CNT_COUNT); }
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
-
-// Lower bound on the distance between any key of sorted range A and any key of sorted range
-// B, from the bases the ranges' own bounds already fix: all keys between lo and hi share
-// every base above the highest bit in which lo and hi differ.  bpb = bits per base in the
-// filter key (2 for 32-bit keys, 3 for 64-bit ones).
-int shared_top_bases(uint64_t lo, uint64_t hi, int umi_len, int bpb)
-{
-    const uint64_t x = lo ^ hi;
-    if (!x) return umi_len;
-    const int hb = 63 - __builtin_clzll(x);
-    return std::max(0, umi_len - 1 - hb / bpb);
-}
-int range_distance_bound(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, int umi_len,
-                         int bpb)
-{
-    const int t = std::min(shared_top_bases(a_lo, a_hi, umi_len, bpb),
-                           shared_top_bases(b_lo, b_hi, umi_len, bpb));
-    int mism = 0;
-    const uint64_t mask = (1ull << bpb) - 1;
-    for (int i = umi_len - t; i < umi_len; i++)
-        mism += ((a_lo >> (bpb * i)) & mask) != ((b_lo >> (bpb * i)) & mask);
-    return mism;
-}
-
-// Tile tasks of the bit-sliced kernel for every large bucket.  samples (prune mode, else
-// null): per bucket the sorted filter keys at positions s, s+128, ..., and e-1.
-void gen_bs_tasks(Plan &pl, int umi_len, uint32_t col_chunk, int k,
-                  const std::vector<std::vector<uint64_t>> *samples, bool key32)
-{
-    const uint32_t gpl = (uint32_t)bs_groups_per_lane(umi_len);
-    const int bpb = key32 ? 2 : 3;
-    for (size_t bi = 0; bi < pl.bs_buckets.size(); bi++) {
-        const Plan::BsBucket &bb = pl.bs_buckets[bi];
-        const uint64_t s = bb.s, e = bb.e;
-        if (bb.live) { // table variant: one record per row tile
-            const uint32_t tile_groups = 64u * (uint32_t)BS_TAB_G;
-            for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
-                const uint64_t r_lo = s + (uint64_t)g0 * 32;
-                pl.tab_rows.push_back(TabRowTile{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off});
-                pl.tab_items_max += (e - r_lo + BS_TAB_TILE - 1) / BS_TAB_TILE;
-                pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (e - r_lo);
-                pl.n_pairs_eval_tab += (uint64_t)tile_groups * 32 * (e - r_lo);
-            }
-            continue;
-        }
-        const uint32_t tile_groups = (bb.wide ? 256u : 64u) * gpl;
-        const std::vector<uint64_t> *smp = samples ? &(*samples)[bi] : nullptr;
-        std::vector<BsTask> &list = pl.bs_tasks[!bb.wide ? 0 : (bb.pu == 3 ? 2 : (bb.pu == 4 ? 3 : 1))];
-        auto key_lo = [&](uint64_t pos) { return (*smp)[(pos - s) / BS_COL_TILE]; };
-        auto key_hi = [&](uint64_t end) { // an upper bound of the last key of [.., end)
-            if (end >= e) return smp->back();
-            const uint64_t idx = (end - s + BS_COL_TILE - 1) / BS_COL_TILE;
-            return idx < smp->size() ? (*smp)[idx] : smp->back();
-        };
-        // two passes: the tasks on the bucket's diagonal first.  They take about three times as
-        // long as the others (the filter hits of a key-sorted bucket crowd there), and the launch
-        // should end on short tasks.  Within a pass the order is row-tile-major, which shares a
-        // row tile's planes in L2.
-        for (int pass = 0; pass < 2; pass++)
-            for (uint32_t g0 = 0; g0 < bb.ngroups; g0 += tile_groups) {
-                const uint64_t r_lo = s + (uint64_t)g0 * 32;
-                const uint64_t r_hi = std::min<uint64_t>(e, r_lo + (uint64_t)tile_groups * 32);
-                // diagonal chunks of a row tile: those that start before its last row
-                const uint64_t c_begin = pass == 0 ? r_lo : r_lo + (r_hi - r_lo + col_chunk - 1) / col_chunk * col_chunk;
-                const uint64_t c_end = pass == 0 ? std::min<uint64_t>(e, c_begin + (r_hi - r_lo + col_chunk - 1) / col_chunk * col_chunk) : e;
-                for (uint64_t c0 = c_begin; c0 < c_end; c0 += col_chunk) {
-                    const uint64_t c1 = std::min<uint64_t>(e, c0 + col_chunk);
-                    const bool diag = c0 < r_hi;
-                    if (smp && !diag &&
-                        range_distance_bound(key_lo(r_lo), key_hi(r_hi), key_lo(c0), key_hi(c1), umi_len,
-                                             bpb) > k) {
-                        pl.n_tasks_pruned++;
-                        continue; // no pair of this tile can be within k
-                    }
-                    list.push_back(BsTask{(uint32_t)s, (uint32_t)e, g0, bb.ngroups, bb.plane_off,
-                                          (uint32_t)c0, (uint32_t)c1, diag ? 1u : 0u, 0u});
-                    pl.n_pairs_eval += (uint64_t)tile_groups * 32 * (c1 - c0);
-                }
-            }
-    }
-}
-
-// Prefix units worth caching for a key-sorted bucket of n entries: the state of the `pu`
-// highest 2-base units is reused along a run of columns that agree in them.  A run of random
-// keys is about n / 4^(bases that vary in the prefix) columns long; below ~4 columns the
-// bookkeeping costs more than it saves.
-int choose_prefix_units(uint64_t n, int umi_len)
-{
-    const int lp = bs_padded_len(umi_len), units = lp / 2, pad = lp - umi_len;
-    for (int pu = 4; pu >= 3; pu--) {
-        if (pu >= units) continue;
-        const int bases = std::max(0, 2 * pu - pad);
-        if ((n >> (2 * bases)) >= 4) return pu;
-    }
-    return 0;
-}
-
-// Table variant (32-bit keys): two live units, if the prefix above them (the other units' bases,
-// less the padding) still gives runs of ~4 columns; 0 otherwise.
-int choose_live_units(uint64_t n, int umi_len, uint32_t min_run)
-{
-    const int lp = bs_padded_len(umi_len), units = lp / 2, pad = lp - umi_len;
-    if (units <= 2) return 0;
-    const int bases = std::max(0, 2 * (units - 2) - pad);
-    return (n >> (2 * bases)) >= min_run ? 2 : 0;
-}
-
-void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
-                int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, bool tables,
-                uint32_t tab_min_run, Plan &pl)
-{
-    pl.n_fused = 0;
-    pl.ranges.clear();
-    uint64_t run_s = 0, run_e = 0; // current run of entries the fused kernel does not take
-    auto close_run = [&]() {
-        for (uint64_t q = run_s; q < run_e; q += RANGE_CHUNK)
-            pl.ranges.push_back({(uint32_t)q, (uint32_t)std::min<uint64_t>(run_e, q + RANGE_CHUNK)});
-        run_s = run_e = 0;
-    };
-    pl.small_tasks.clear();
-    pl.big_tasks.clear();
-    for (auto &v : pl.bs_tasks) v.clear();
-    pl.tab_rows.clear();
-    pl.tab_items_max = 0;
-    pl.n_pairs_eval_tab = 0;
-    pl.plane_tasks.clear();
-    pl.bs_buckets.clear();
-    pl.plane_words = 0;
-    pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = pl.n_tasks_pruned = 0;
-    const uint32_t np = 2 * (uint32_t)bs_padded_len(umi_len);
-    for (uint64_t b = 0; b < n_buckets; b++) {
-        const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
-        const uint64_t n = e - s;
-        pl.max_bucket = std::max(pl.max_bucket, n);
-        if (n > fused_max) { // prep and finalize are this bucket's (runs of neighbours merge)
-            if (run_e != s) {
-                close_run();
-                run_s = s;
-            }
-            run_e = e;
-        }
-        if (n < 2) continue;
-        pl.n_pairs += n * (n - 1) / 2;
-        if (n <= fused_max) {
-            pl.n_fused++;
-            pl.n_pairs_eval += n * n;
-        } else if (n <= small_max) {
-            for (uint64_t r0 = s; r0 < e; r0 += SMALL_ROWS) {
-                pl.small_tasks.push_back({(uint32_t)r0, (uint32_t)e, (uint32_t)r0, (uint32_t)e});
-                pl.n_pairs_eval += (uint64_t)SMALL_ROWS * (((e - r0) + 31) / 32 * 32);
-            }
-        } else if (use_bs) {
-            const uint32_t ngroups = (uint32_t)((n + 31) / 32);
-            // prune mode wants small row tiles: the shorter the key range of a tile, the more
-            // leading bases it fixes and the more column chunks it can rule out
-            const bool wide = !narrow_only && n >= (uint64_t)BS_WIDE_MIN;
-            for (uint32_t g = 0; g < ngroups; g += 2)
-                pl.plane_tasks.push_back(
-                    {(uint32_t)(s + (uint64_t)g * 32), (uint32_t)e, pl.plane_words, ngroups, g});
-            int live = wide && cache_prefix && tables ? choose_live_units(n, umi_len, tab_min_run) : 0;
-            // (its item list is sized for the worst case, every column tile of every row tile)
-            if (live && (n / (64u * BS_TAB_G * 32u) + 1) * (n / BS_TAB_TILE + 1) / 2 > (1ull << 26)) live = 0;
-            pl.bs_buckets.push_back({s, e, pl.plane_words, ngroups, wide,
-                                     wide && cache_prefix && !live ? choose_prefix_units(n, umi_len) : 0, live});
-            pl.plane_words += (uint64_t)np * ngroups;
-        } else {
-            for (uint64_t r0 = s; r0 < e; r0 += BIG_ROWS) {
-                for (uint64_t c0 = r0; c0 < e; c0 += BIG_COL_CHUNK) {
-                    const uint64_t c1 = std::min<uint64_t>(e, c0 + BIG_COL_CHUNK);
-                    pl.big_tasks.push_back(
-                        {(uint32_t)r0, (uint32_t)e, (uint32_t)c0, (uint32_t)c1});
-                    pl.n_pairs_eval += (uint64_t)BIG_ROWS * (((c1 - c0) + 31) / 32 * 32);
-                }
-            }
-        }
-    }
-    close_run();
-}
 
 int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
                  int algo, uint64_t *n_out)
@@ -360,16 +186,16 @@ int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, i
 template <class LaunchRound>
 int run_rounds(umi_ctx *ctx, hipStream_t s, LaunchRound launch_round, int &rounds, int batch = 4)
 {
-    uint32_t *d_changed = ctx->changed.as<uint32_t>();
+    uint32_t *d_changed = ctx->d_changed();
     for (;;) {
         HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * MAX_ROUNDS_PER_SYNC, s));
         for (int r = 0; r < batch; r++) HIP_TRY(launch_round(d_changed, r));
-        HIP_TRY(hipMemcpyAsync(ctx->h_changed, d_changed, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_changed(), d_changed, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         bool done = false;
         for (int r = 0; r < batch && !done; r++) {
             rounds++;
-            done = ctx->h_changed[r] == 0;
+            done = ctx->h_changed()[r] == 0;
         }
         if (done) return UMI_OK;
         if (rounds > MAX_ROUNDS) return fail(UMI_ERR_HIP, "label propagation diverged");
@@ -390,11 +216,16 @@ int directional_labels(umi_ctx *ctx, const uint2 *d_edges, unsigned long long *d
         }, rounds);
     if ((rc = ctx->lab.reserve((size_t)n * 4))) return rc;
     uint32_t *d_lab = ctx->lab.as<uint32_t>();
-    HIP_TRY(launch_iota(d_lab, n, s));
-    if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
-             return launch_cc_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
-         }, rounds, 6))) // a giant component of 10^6 entries settles in 5
-        return rc;
+    if (ctx->two_phase == 2) {
+        HIP_TRY(launch_uf_components(d_edges, d_cnt, edge_cap, d_label, d_lab, n, (uint32_t)n_edges, s));
+        rounds++;
+    } else {
+        HIP_TRY(launch_iota(d_lab, n, s));
+        if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
+                 return launch_cc_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
+             }, rounds, 6))) // a giant component of 10^6 entries settles in 5
+            return rc;
+    }
     if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
              return launch_dag_round(d_edges, d_cnt, edge_cap, d_label, d_lab, n, d_changed, r,
                                      (uint32_t)n_edges, s);
@@ -471,17 +302,39 @@ class Pipeline {
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
     const uint32_t *bs_perm = nullptr;
+    // device tables of the plan (inside ctx->plan_tables)
+    const RangeTask *d_ranges = nullptr;
+    const SegDesc *d_segs = nullptr;
+    const SegScanChunk *d_chunks = nullptr;
+    const PairTask *d_small = nullptr, *d_big = nullptr;
+    SegArgs seg;
+
+    // The bit-sliced tile kernels of the earlier versions (options bs_sorted / bs_tables / prune,
+    // k > the segment index's reach, seg_index = 0) keep their own overflow list, which the host
+    // has to look at between the pair stage and the collapse.
+    bool legacy_tiles() const { return pl.n_bs() || !pl.tab_rows.empty(); }
+    // Everything of a call enqueued back to back, one synchronisation at the end: the batched
+    // directional path (and the reference's adjacency, which needs no pairs) without those tiles.
+    bool one_sync() const
+    {
+        return (mode == MODE_DIRECTIONAL || !need_pairs) && n_parts == 1 && ctx->two_phase == 2 && !legacy_tiles();
+    }
 
     int run_stages()
     {
         int rc;
         // The fused kernel needs nothing from the plan (it walks the bucket table itself and does
-        // everything for its buckets): it is enqueued first, and the host walks the table -- tile
-        // tasks, pair counts, the entry ranges left for prep and finalize -- while it runs.
+        // everything for its buckets): with many buckets it is enqueued first, and the host walks
+        // the table -- tile tasks, pair counts, the entry ranges left for prep and finalize --
+        // while it runs.  With few buckets the plan is there at once and says whether any bucket
+        // is the fused kernel's at all.
         if ((rc = reserve_core())) return rc;
         if ((rc = upload_table())) return rc;
-        if ((rc = fused_stage())) return rc;
-        if ((rc = plan_and_upload_tasks())) return rc;
+        const bool plan_first = n_buckets <= 4096;
+        if (plan_first) plan_host();
+        if ((!plan_first || pl.n_fused) && (rc = fused_stage())) return rc;
+        if (!plan_first) plan_host();
+        if ((rc = upload_plan())) return rc;
         if ((rc = prep_stage())) return rc;
         if (prune) {
             if ((rc = prune_stage())) return rc;
@@ -492,7 +345,10 @@ class Pipeline {
             gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
             for (auto &v : pl.bs_tasks) keep_my_share(v);
         }
+        if (need_pairs && pl.seg_parts)
+            HIP_TRY(launch_seg_build(seg, ctx->fkey.p, d_freq, key32, d_cnt, s));
         if ((rc = upload_bitsliced())) return rc;
+        if (one_sync()) return run_one_sync();
         if ((rc = pair_stage())) return rc;
         if (mode == MODE_NEIGHBOURS || n_parts > 1) return finish_neighbours();
         if (mode == MODE_DIRECTIONAL || !need_pairs)
@@ -517,30 +373,28 @@ class Pipeline {
         v.resize(w);
     }
 
-    int sync_counters()
+    int read_control()
     {
-        HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CNT_COUNT * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CTRL_BYTES, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const unsigned long long bad =
             ctx->h_counters[CNT_ERROR] + (ctx->h_counters[CNT_RISES] - ctx->h_counters[CNT_START_RISES]);
         if (bad)
             return fail(UMI_ERR_ORDER,
-                        "%llu entries break the input contract (freq < 1 or not in "
-                        "freq-descending rank order inside a bucket)",
+                        "%llu entries break the input contract (freq < 1, not in freq-descending rank "
+                        "order inside a bucket, or an N base without nmask)",
                         bad);
         return UMI_OK;
     }
+    int sync_counters() { return read_control(); }
 
     // workspace whose size follows from n and n_buckets alone
     int reserve_core()
     {
         int rc;
         if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
-            (rc = ctx->label.reserve((size_t)n * 4)) ||
-            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
-            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))) ||
-            (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
+            (rc = ctx->label.reserve((size_t)n * 4)) || (rc = ctx->lab.reserve((size_t)n * 4)) ||
+            (rc = ctx->counters.reserve(CTRL_BYTES)) || (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
             return rc;
         if (mode == MODE_ADJACENCY && need_pairs)
             if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
@@ -549,39 +403,90 @@ class Pipeline {
         return UMI_OK;
     }
 
-    // host planning (overlaps the prep kernels) + the popcount kernels' task lists
-    int plan_and_upload_tasks()
+    // host planning: which kernel takes which bucket
+    void plan_host()
     {
+        const bool seg_on = ctx->seg_index && need_pairs && !ctx->prune;
         build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
                    umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
-                   ctx->bs_tables && key32, ctx->bs_tab_min_run, pl);
+                   ctx->bs_tables && key32, ctx->bs_tab_min_run, seg_on ? std::max(ctx->seg_min, 1u) : 0u, k, key32, pl);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
         keep_my_share(pl.small_tasks);
         keep_my_share(pl.big_tasks);
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
+    }
+
+    // the plan's tables -- entry ranges, segment descriptors and scan chunks, popcount tile tasks --
+    // through one pinned block and one copy; workspace whose size the plan gives
+    int upload_plan()
+    {
         int rc;
-        if ((rc = ctx->tasks.reserve(std::max<size_t>(1, pl.small_tasks.size() + pl.big_tasks.size()) *
-                                     sizeof(PairTask))) ||
-            (rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) *
-                                           sizeof(PlaneTask))) ||
+        size_t off = 0;
+        auto place = [&](size_t bytes) {
+            const size_t at = off;
+            off = (off + bytes + 63) & ~(size_t)63;
+            return at;
+        };
+        const size_t o_ranges = place(pl.ranges.size() * sizeof(RangeTask));
+        const size_t o_segs = place(pl.segs.size() * sizeof(SegDesc));
+        const size_t o_chunks = place(pl.seg_chunks.size() * sizeof(SegScanChunk));
+        const size_t o_small = place(pl.small_tasks.size() * sizeof(PairTask));
+        const size_t o_big = place(pl.big_tasks.size() * sizeof(PairTask));
+        const size_t total = std::max<size_t>(off, 64);
+        if ((rc = ctx->h_plan.reserve(total)) || (rc = ctx->plan_tables.reserve(total))) return rc;
+        if ((rc = ctx->h_plan.put(o_ranges, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask))) ||
+            (rc = ctx->h_plan.put(o_segs, pl.segs.data(), pl.segs.size() * sizeof(SegDesc))) ||
+            (rc = ctx->h_plan.put(o_chunks, pl.seg_chunks.data(), pl.seg_chunks.size() * sizeof(SegScanChunk))) ||
+            (rc = ctx->h_plan.put(o_small, pl.small_tasks.data(), pl.small_tasks.size() * sizeof(PairTask))) ||
+            (rc = ctx->h_plan.put(o_big, pl.big_tasks.data(), pl.big_tasks.size() * sizeof(PairTask))))
+            return rc;
+        if (off) HIP_TRY(hipMemcpyAsync(ctx->plan_tables.p, ctx->h_plan.p, off, hipMemcpyHostToDevice, s));
+        const char *d = (const char *)ctx->plan_tables.p;
+        d_ranges = (const RangeTask *)(d + o_ranges);
+        d_segs = (const SegDesc *)(d + o_segs);
+        d_chunks = (const SegScanChunk *)(d + o_chunks);
+        d_small = (const PairTask *)(d + o_small);
+        d_big = (const PairTask *)(d + o_big);
+
+        if ((rc = ctx->plane_tasks.reserve(std::max<size_t>(1, pl.plane_tasks.size()) * sizeof(PlaneTask))) ||
             (rc = ctx->planes.reserve(std::max<uint64_t>(1, pl.plane_words) * sizeof(uint32_t))))
             return rc;
-        PairTask *d_tasks = ctx->tasks.as<PairTask>();
-        if (!pl.small_tasks.empty())
-            HIP_TRY(hipMemcpyAsync(d_tasks, pl.small_tasks.data(),
-                                   pl.small_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
-        if (!pl.big_tasks.empty())
-            HIP_TRY(hipMemcpyAsync(d_tasks + pl.small_tasks.size(), pl.big_tasks.data(),
-                                   pl.big_tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice, s));
+        memset(&seg, 0, sizeof(seg));
+        if (pl.seg_parts && need_pairs) {
+            if (pl.seg_task_cap > 0x7FFFFFF0ull / sizeof(SegTask) || pl.seg_bins > 0x7FFFFFF0ull ||
+                pl.seg_entries * (uint64_t)pl.seg_parts > 0x7FFFFFF0ull)
+                return fail(UMI_ERR_NOMEM, "segment index of this call too large (set seg_index=0)");
+            const size_t m = (size_t)pl.seg_entries * (size_t)pl.seg_parts;
+            if ((rc = ctx->seg_bin_cnt.reserve(pl.seg_bins * 4)) || (rc = ctx->seg_bin_start.reserve(pl.seg_bins * 4)) ||
+                (rc = ctx->seg_chunk_sums.reserve(pl.seg_chunks.size() * sizeof(uint2))) ||
+                (rc = ctx->seg_tasks.reserve(pl.seg_task_cap * sizeof(SegTask))) ||
+                (rc = ctx->seg_sub_rec.reserve(m * sizeof(SegRec32))))
+                return rc;
+            static_assert(sizeof(SegRec32) == 16 && sizeof(SegRec64) == 16, "one 16-byte store per record");
+            seg.segs = d_segs;
+            seg.chunks = d_chunks;
+            seg.n_chunks = (uint32_t)pl.seg_chunks.size();
+            seg.n_parts = pl.seg_parts;
+            seg.bin_cnt = ctx->seg_bin_cnt.as<uint32_t>();
+            seg.bin_start = ctx->seg_bin_start.as<uint32_t>();
+            seg.chunk_sums = ctx->seg_chunk_sums.as<uint2>();
+            seg.tasks = ctx->seg_tasks.as<SegTask>();
+            seg.task_cap = (uint32_t)pl.seg_task_cap;
+            seg.sub_rec = ctx->seg_sub_rec.p;
+            seg.ranges = d_ranges;
+            seg.n_ranges = (uint32_t)pl.ranges.size();
+            seg.dbg = ctx->seg_dbg;
+            HIP_TRY(hipMemsetAsync(seg.bin_cnt, 0, pl.seg_bins * 4, s));
+        }
         return UMI_OK;
     }
 
-    // counters, bucket table
+    // control block, bucket table
     int upload_table()
     {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        HIP_TRY(hipMemsetAsync(d_cnt, 0, CNT_COUNT * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, CTRL_BYTES, s));
         // the bucket table goes through a pinned buffer: a true async DMA instead of the
         // runtime's staged copy of pageable memory (it is on the critical path of prep)
         if (ctx->h_boff_cap < n_buckets + 1) {
@@ -624,18 +529,14 @@ class Pipeline {
         return UMI_OK;
     }
 
-    // filter keys / thresholds / labels / contract check of the entries the fused kernel left
+    // filter keys / thresholds / labels / contract check of the entries the fused kernel left;
+    // the entries of a segment also count themselves into the bins of its parts
     int prep_stage()
     {
-        int rc;
-        if ((rc = ctx->ranges.reserve(std::max<size_t>(1, pl.ranges.size()) * sizeof(RangeTask)))) return rc;
-        if (!pl.ranges.empty())
-            HIP_TRY(hipMemcpyAsync(ctx->ranges.p, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask),
-                                   hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets,
-                            ctx->ranges.as<RangeTask>(), (uint32_t)pl.ranges.size(), n, fused_max, umi_len,
-                            percentage, key32, ctx->fkey.p, ctx->thr.as<int32_t>(),
-                            ctx->label.as<uint32_t>(), d_cnt, s));
+        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, d_ranges,
+                            (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
+                            ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), d_cnt,
+                            seg.n_chunks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
         return UMI_OK;
     }
 
@@ -720,12 +621,13 @@ class Pipeline {
         return UMI_OK;
     }
 
-    // bit-sliced tile tasks + bit planes of the large buckets
+    // bit-sliced tile tasks + bit planes of the large buckets the segment index does not take
     int upload_bitsliced()
     {
-        n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + pl.tab_rows.size();
+        n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + pl.tab_rows.size() +
+                  (pl.seg_parts ? 1 : 0);
         if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
-        if (need_pairs && (pl.n_bs() || !pl.tab_rows.empty())) {
+        if (need_pairs && legacy_tiles()) {
             int rc;
             if (pl.tab_items_max > 0x7FFFFFF0ull / sizeof(TabItem))
                 return fail(UMI_ERR_NOMEM, "item list of the table kernel too large (set bs_tables=0)");
@@ -738,25 +640,18 @@ class Pipeline {
             const size_t bs_bytes = pl.n_bs() * sizeof(BsTask);
             const size_t plane_bytes = pl.plane_tasks.size() * sizeof(PlaneTask);
             const size_t row_bytes = pl.tab_rows.size() * sizeof(TabRowTile);
-            if (ctx->h_tasks_cap < bs_bytes + plane_bytes + row_bytes) {
-                if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
-                ctx->h_tasks = nullptr;
-                ctx->h_tasks_cap = 0;
-                const size_t want = (bs_bytes + plane_bytes + row_bytes) * 5 / 4 + 4096;
-                HIP_TRY(hipHostMalloc(&ctx->h_tasks, want));
-                ctx->h_tasks_cap = want;
-            }
-            char *h = (char *)ctx->h_tasks;
+            if ((rc = ctx->h_tasks.reserve(bs_bytes + plane_bytes + row_bytes))) return rc;
+            const char *h = ctx->h_tasks.p;
             size_t off = 0;
             for (auto &v : pl.bs_tasks) {
-                memcpy(h + off, v.data(), v.size() * sizeof(BsTask));
+                if ((rc = ctx->h_tasks.put(off, v.data(), v.size() * sizeof(BsTask)))) return rc;
                 off += v.size() * sizeof(BsTask);
             }
             if (row_bytes) {
-                memcpy(h + bs_bytes + plane_bytes, pl.tab_rows.data(), row_bytes);
+                if ((rc = ctx->h_tasks.put(bs_bytes + plane_bytes, pl.tab_rows.data(), row_bytes))) return rc;
                 HIP_TRY(hipMemcpyAsync(ctx->tab_rows.p, h + bs_bytes + plane_bytes, row_bytes, hipMemcpyHostToDevice, s));
             }
-            memcpy(h + bs_bytes, pl.plane_tasks.data(), plane_bytes);
+            if ((rc = ctx->h_tasks.put(bs_bytes, pl.plane_tasks.data(), plane_bytes))) return rc;
             if (bs_bytes) HIP_TRY(hipMemcpyAsync(ctx->bs_tasks.p, h, bs_bytes, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(ctx->plane_tasks.p, h + bs_bytes, plane_bytes, hipMemcpyHostToDevice, s));
             HIP_TRY(launch_build_planes(bs_fkey, key32, ctx->plane_tasks.as<PlaneTask>(),
@@ -765,6 +660,95 @@ class Pipeline {
         }
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[1], s));
         return UMI_OK;
+    }
+
+    // lists the pair kernels append to
+    int reserve_lists(uint64_t cap, uint64_t &ovf_cap)
+    {
+        int rc;
+        if (cap > 0x7FFFFFF0ull) return fail(UMI_ERR_NOMEM, "edge list too large");
+        if ((rc = ctx->edges.reserve(cap * sizeof(uint2)))) return rc;
+        if (mode == MODE_NEIGHBOURS && (rc = ctx->edge_dist.reserve(cap))) return rc;
+        cap_used = (uint32_t)cap;
+        ovf_cap = std::min<uint64_t>(std::max<uint64_t>(ctx->ovf_capacity, 1024), 0x7FFFFFF0ull);
+        if (legacy_tiles() && (rc = ctx->ovf.reserve(ovf_cap * sizeof(uint2)))) return rc;
+        return UMI_OK;
+    }
+
+    // all pair kernels of the call, largest work first (nothing waits on the host in here)
+    int enqueue_pairs(uint64_t ovf_cap)
+    {
+        PairArgs a;
+        a.keys = d_keys;
+        a.nmask = d_nmask;
+        a.freq = d_freq;
+        a.thr = ctx->thr.as<int32_t>();
+        a.fkey = ctx->fkey.p;
+        a.tasks = d_small;
+        a.bs_tasks = ctx->bs_tasks.as<BsTask>();
+        a.planes = ctx->planes.as<uint32_t>();
+        a.perm = nullptr;
+        a.edges = ctx->edges.as<uint2>();
+        a.edge_dist = ctx->edge_dist.as<uint8_t>();
+        a.counters = d_cnt;
+        a.ovf = ctx->ovf.as<uint2>();
+        a.ovf_cap = (uint32_t)ovf_cap;
+        a.edge_cap = cap_used;
+        a.k = k;
+        a.mode = mode;
+        a.adj_max_freq = adj_max_freq;
+        a.n_entries = n;
+        if (pl.seg_parts) { // the large buckets' sub-buckets: persistent one-wave blocks
+            const uint32_t blocks = std::max(1u, (uint32_t)std::min<uint64_t>(
+                pl.seg_task_cap, ctx->seg_blocks ? ctx->seg_blocks : (uint64_t)ctx->n_cus * 24));
+            int rc;
+            if ((rc = ctx->seg_priv_edges.reserve((size_t)blocks * SEG_PRIV_CAP * sizeof(uint2))) ||
+                (rc = ctx->seg_priv_cnt.reserve((size_t)blocks * 4)) ||
+                (mode == MODE_NEIGHBOURS && (rc = ctx->seg_priv_dist.reserve((size_t)blocks * SEG_PRIV_CAP))))
+                return rc;
+            seg.priv_edges = ctx->seg_priv_edges.as<uint2>();
+            seg.priv_dist = ctx->seg_priv_dist.as<uint8_t>();
+            seg.priv_cnt = ctx->seg_priv_cnt.as<uint32_t>();
+            HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
+            st.n_pair_launches += 1;
+        }
+        PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays
+        b.fkey = bs_fkey;
+        b.perm = bs_perm;
+        if (!pl.tab_rows.empty()) // the table variant first (the largest buckets)
+            HIP_TRY(launch_bs_tab(b, ctx->tab_rows.as<TabRowTile>(), (uint32_t)pl.tab_rows.size(),
+                                  ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
+                                  n_parts,
+                                  ctx->bs_tab_waves ? ctx->bs_tab_waves
+                                                    : (ctx->bs_transposed ? 128u : 16u) * (uint32_t)ctx->n_cus,
+                                  ctx->bs_transposed, s));
+        size_t first = pl.n_bs();
+        for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
+            first -= pl.bs_tasks[li].size();
+            PairArgs w = b;
+            w.bs_tasks = b.bs_tasks + first;
+            HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
+                                    ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
+        }
+        PairArgs big = a;
+        big.tasks = d_big;
+        HIP_TRY(launch_pairs(big, (uint32_t)pl.big_tasks.size(), true, key32, s));
+        HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
+        for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
+        st.n_pair_launches += pl.tab_rows.empty() ? 0 : 2;
+        st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
+        return UMI_OK;
+    }
+
+    void note_pair_counters()
+    {
+        n_edges = ctx->h_counters[CNT_EDGES];
+        st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
+        st.n_pairs_evaluated = pl.n_pairs_eval + ctx->h_counters[CNT_SEG_PAIRS];
+        if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
+            st.n_pairs_evaluated = st.n_pairs_evaluated - pl.n_pairs_eval_tab +
+                                   (ctx->h_counters[CNT_ITEMS] + ctx->h_counters[CNT_DIAG_ITEMS]) *
+                                       (64ull * BS_TAB_G * 32) * BS_TAB_TILE;
     }
 
     // all-pairs: fused small buckets straight to label[]/status[]; tile kernels to the edge list
@@ -778,58 +762,9 @@ class Pipeline {
         int rc;
         uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
         for (int attempt = 0;; attempt++) {
-            if (cap > 0x7FFFFFF0ull) return fail(UMI_ERR_NOMEM, "edge list too large");
-            if ((rc = ctx->edges.reserve(cap * sizeof(uint2)))) return rc;
-            if (mode == MODE_NEIGHBOURS && (rc = ctx->edge_dist.reserve(cap))) return rc;
-            cap_used = (uint32_t)cap;
-            uint64_t ovf_cap = std::min<uint64_t>(std::max<uint64_t>(ctx->ovf_capacity, 1024), 0x7FFFFFF0ull);
-            if ((rc = ctx->ovf.reserve(ovf_cap * sizeof(uint2)))) return rc;
-            PairArgs a;
-            a.keys = d_keys;
-            a.nmask = d_nmask;
-            a.freq = d_freq;
-            a.thr = ctx->thr.as<int32_t>();
-            a.fkey = ctx->fkey.p;
-            a.tasks = ctx->tasks.as<PairTask>();
-            a.bs_tasks = ctx->bs_tasks.as<BsTask>();
-            a.planes = ctx->planes.as<uint32_t>();
-            a.perm = nullptr;
-            a.edges = ctx->edges.as<uint2>();
-            a.edge_dist = ctx->edge_dist.as<uint8_t>();
-            a.counters = d_cnt;
-            a.ovf = ctx->ovf.as<uint2>();
-            a.ovf_cap = (uint32_t)ovf_cap;
-            a.edge_cap = cap_used;
-            a.k = k;
-            a.mode = mode;
-            a.adj_max_freq = adj_max_freq;
-            a.n_entries = n;
-            // largest work first: wide bit-sliced tiles, column-split ones, then the popcount kernels
-            PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays in prune mode
-            b.fkey = bs_fkey;
-            b.perm = bs_perm;
-            if (!pl.tab_rows.empty()) // the table variant first (the largest buckets)
-                HIP_TRY(launch_bs_tab(b, ctx->tab_rows.as<TabRowTile>(), (uint32_t)pl.tab_rows.size(),
-                                      ctx->tab_items.as<TabItem>(), (uint32_t)pl.tab_items_max, umi_len, part,
-                                      n_parts,
-                                      ctx->bs_tab_waves ? ctx->bs_tab_waves
-                                                        : (ctx->bs_transposed ? 128u : 16u) * (uint32_t)ctx->n_cus,
-                                      ctx->bs_transposed, s));
-            size_t first = pl.n_bs();
-            for (int li = 3; li >= 0; li--) { // lists sit in the device array in index order
-                first -= pl.bs_tasks[li].size();
-                PairArgs w = b;
-                w.bs_tasks = b.bs_tasks + first;
-                HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
-                                        ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
-            }
-            PairArgs big = a;
-            big.tasks = a.tasks + pl.small_tasks.size();
-            HIP_TRY(launch_pairs(big, (uint32_t)pl.big_tasks.size(), true, key32, s));
-            HIP_TRY(launch_pairs(a, (uint32_t)pl.small_tasks.size(), false, key32, s));
-            for (auto &v : pl.bs_tasks) st.n_pair_launches += v.empty() ? 0 : 1;
-            st.n_pair_launches += pl.tab_rows.empty() ? 0 : 2;
-            st.n_pair_launches += (pl.small_tasks.empty() ? 0 : 1) + (pl.big_tasks.empty() ? 0 : 1);
+            uint64_t ovf_cap = 0;
+            if ((rc = reserve_lists(cap, ovf_cap))) return rc;
+            if ((rc = enqueue_pairs(ovf_cap))) return rc;
             if ((rc = sync_counters())) return rc;
             // filter hits that did not fit the blocks' LDS queues (very dense tiles): checked now,
             // or -- if their list ran over as well -- everything again with a longer list
@@ -839,17 +774,30 @@ class Pipeline {
                 ctx->ovf_capacity = n_ovf + n_ovf / 8 + 1024;
                 redo = true;
             } else if (n_ovf) {
+                PairArgs b;
+                memset(&b, 0, sizeof(b));
+                b.keys = d_keys;
+                b.nmask = d_nmask;
+                b.freq = d_freq;
+                b.thr = ctx->thr.as<int32_t>();
+                b.fkey = bs_fkey;
+                b.perm = bs_perm;
+                b.edges = ctx->edges.as<uint2>();
+                b.edge_dist = ctx->edge_dist.as<uint8_t>();
+                b.counters = d_cnt;
+                b.ovf = ctx->ovf.as<uint2>();
+                b.ovf_cap = (uint32_t)ovf_cap;
+                b.edge_cap = cap_used;
+                b.k = k;
+                b.mode = mode;
+                b.adj_max_freq = adj_max_freq;
+                b.n_entries = n;
                 HIP_TRY(launch_verify_list(b, key32, (uint32_t)n_ovf, s));
                 st.n_pair_launches += 1;
                 if ((rc = sync_counters())) return rc;
             }
             if (prof && !redo) HIP_TRY(hipEventRecord(ctx->ev[2], s));
-            n_edges = ctx->h_counters[CNT_EDGES];
-            st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
-            if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
-                st.n_pairs_evaluated = pl.n_pairs_eval - pl.n_pairs_eval_tab +
-                                       (ctx->h_counters[CNT_ITEMS] + ctx->h_counters[CNT_DIAG_ITEMS]) *
-                                           (64ull * BS_TAB_G * 32) * BS_TAB_TILE;
+            note_pair_counters();
             if (!redo && n_edges <= cap) break;
             if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
             if (n_edges > cap) {
@@ -861,6 +809,67 @@ class Pipeline {
         }
         st.n_edges = n_edges;
         return UMI_OK;
+    }
+
+    // The batched directional path with one synchronisation: pair kernels, union-find over the
+    // symmetric pairs, DAG_ROUNDS rounds along the one-way pairs, kept mask -- all enqueued behind
+    // one another (the kernels read the edge count on the device), the control block read once.
+    // What the host may find then: the edge list ran over (longer list, pairs and collapse
+    // again), or the last one-way round still moved a label (more rounds, finalize again).
+    int run_one_sync()
+    {
+        int rc;
+        uint32_t *d_label = ctx->label.as<uint32_t>(), *d_lab = ctx->lab.as<uint32_t>();
+        uint32_t *d_changed = ctx->d_changed();
+        const bool have_pairs = need_pairs && n_tasks;
+        uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
+        for (int attempt = 0;; attempt++) {
+            if (have_pairs) {
+                uint64_t ovf_cap = 0;
+                if ((rc = reserve_lists(cap, ovf_cap))) return rc;
+                if ((rc = enqueue_pairs(ovf_cap))) return rc;
+            }
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
+            const uint2 *d_edges = ctx->edges.as<uint2>();
+            if (have_pairs) {
+                HIP_TRY(launch_uf_components(d_edges, d_cnt, cap_used, d_label, d_lab, n, cap_used, s));
+                for (int r = 0; r < DAG_ROUNDS; r++)
+                    HIP_TRY(launch_dag_round(d_edges, d_cnt, cap_used, d_label, d_lab, n, d_changed, r, cap_used, s));
+            }
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
+            if (have_pairs)
+                HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root,
+                                            d_cnt, s));
+            else // no pair of this call reaches the edge list: every entry outside the fused buckets survives
+                HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
+            if ((rc = read_control())) return rc;
+            note_pair_counters();
+            if (n_edges <= cap || !have_pairs) break;
+            if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
+            // the list was too short: the exact count is known now
+            cap = n_edges + n_edges / 16 + 1024;
+            ctx->edge_capacity = cap;
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1), s));
+            HIP_TRY(launch_iota(d_label, n, s)); // (the fused buckets' entries are finished: their labels are free)
+        }
+        st.n_edges = n_edges;
+        int rounds = have_pairs && n_edges ? 1 : 0;
+        for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
+        if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
+            const uint2 *d_edges = ctx->edges.as<uint2>();
+            if ((rc = run_rounds(ctx, s, [&](uint32_t *dc, int r) {
+                     return launch_dag_round(d_edges, d_cnt, cap_used, d_label, d_lab, n, dc, r, cap_used, s);
+                 }, rounds, 4)))
+                return rc;
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
+            HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
+            if ((rc = read_control())) return rc;
+        }
+        st.n_rounds = (uint32_t)rounds;
+        return finish_stats();
     }
 
     int finish_neighbours()
@@ -891,7 +900,7 @@ class Pipeline {
             st.n_rounds = (uint32_t)rounds;
         }
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
-        HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), ctx->ranges.as<RangeTask>(), (uint32_t)pl.ranges.size(), n,
+        HIP_TRY(launch_finalize(ctx->label.as<uint32_t>(), d_ranges, (uint32_t)pl.ranges.size(), n,
                                 d_kept, d_root, d_cnt, s));
         return UMI_OK;
     }
@@ -915,7 +924,7 @@ class Pipeline {
         }
         st.n_rounds = (uint32_t)iters;
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
-        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), ctx->ranges.as<RangeTask>(),
+        HIP_TRY(launch_adj_finalize(d_status, ctx->label.as<uint32_t>(), d_ranges,
                                     (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
         return UMI_OK;
     }
@@ -925,8 +934,14 @@ class Pipeline {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
         int rc = sync_counters();
         if (rc) return rc;
+        return finish_stats();
+    }
+
+    // (the control block has just been read and the stream is idle)
+    int finish_stats()
+    {
         drained = true;
-        st.n_kept = ctx->h_counters[CNT_KEPT];
+        st.n_kept = ctx->h_counters[CNT_KEPT] + ctx->h_counters[CNT_KEPT_FUSED];
         if (prof) {
             hipEvent_t *ev = ctx->ev;
             HIP_TRY(hipEventElapsedTime(&st.ms_prep, ev[0], ev[1]));
@@ -977,9 +992,7 @@ class EdgeCollapse {
     int stages(umi_stats *stats)
     {
         int rc;
-        if ((rc = ctx->label.reserve((size_t)n * 4)) ||
-            (rc = ctx->counters.reserve(CNT_COUNT * sizeof(unsigned long long))) ||
-            (rc = ctx->changed.reserve(sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1))))
+        if ((rc = ctx->label.reserve((size_t)n * 4)) || (rc = ctx->counters.reserve(CTRL_BYTES)))
             return rc;
         if (mode == MODE_ADJACENCY && ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))))
             return rc;
@@ -1069,9 +1082,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (err == hipSuccess)
-        err = hipHostMalloc((void **)&ctx->h_counters, CNT_COUNT * sizeof(unsigned long long));
-    if (err == hipSuccess)
-        err = hipHostMalloc((void **)&ctx->h_changed, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1));
+        err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES);
     for (int i = 0; i < 8 && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
     if (err != hipSuccess) {
         umi_ctx_destroy(ctx);
@@ -1085,17 +1096,19 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->ranges, &ctx->fkey_sorted, &ctx->perm,
+    DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->plan_tables, &ctx->fkey_sorted, &ctx->perm,
+                      &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_chunk_sums, &ctx->seg_tasks,
+                      &ctx->seg_sub_rec, &ctx->seg_priv_edges, &ctx->seg_priv_dist, &ctx->seg_priv_cnt,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
-                      &ctx->edge_dist, &ctx->tasks,  &ctx->counters, &ctx->changed,
+                      &ctx->edge_dist, &ctx->counters,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
                       &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
-    if (ctx->h_tasks) (void)hipHostFree(ctx->h_tasks);
+    ctx->h_tasks.release();
+    ctx->h_plan.release();
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
     for (int i = 0; i < 8; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1120,7 +1133,18 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "bs_tables")) {
         ctx->bs_tables = value != 0;
     } else if (!strcmp(name, "two_phase")) {
-        ctx->two_phase = value != 0;
+        if (value < 0 || value > 2) return fail(UMI_ERR_ARG, "two_phase must be 0, 1 or 2");
+        ctx->two_phase = (int)value;
+    } else if (!strcmp(name, "seg_index")) {
+        ctx->seg_index = value != 0;
+    } else if (!strcmp(name, "seg_dbg")) {
+        ctx->seg_dbg = (uint32_t)value;
+    } else if (!strcmp(name, "seg_blocks")) {
+        if (value < 0 || value > (1 << 22)) return fail(UMI_ERR_ARG, "seg_blocks must be in 0..2^22");
+        ctx->seg_blocks = (uint32_t)value;
+    } else if (!strcmp(name, "seg_min")) {
+        if (value < 2 || value > (1ll << 31)) return fail(UMI_ERR_ARG, "seg_min must be in 2..2^31");
+        ctx->seg_min = (uint32_t)value;
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_max")) {

@@ -1,0 +1,154 @@
+// Directional collapse, phase 1 by union-find (gfx950).
+//
+// What it replaces in the reference (tkob-vh/umi-collapse-rs): Directional::visit_and_remove and
+// the root loop of Directional::apply (src/algo/directional.rs:30-54,78-88), as in
+// umihip_kernels.hip: label[v] = smallest rank that reaches v.  Reachability inside a set of
+// entries joined by symmetric pairs (both directions permitted) is symmetric, so those sets are
+// plain connected components; this file finds them with a lock-free union-find over the edge list
+// (one pass, any number of hops) where the hook/jump rounds of cc_hook_kernel need one launch per
+// halving of the longest chain.  The one-way pairs (a DAG over the sets) are then propagated by
+// dag_hook_kernel as before.
+#include <hip/hip_runtime.h>
+
+#include "umihip_internal.h"
+#include "umihip_device.h"
+
+namespace umihip {
+
+namespace {
+
+// parent[] is read and written with agent-scope accesses (sc1: past the CU's L1, which other CUs'
+// stores never refresh).  parent[v] <= v always (an entry is only ever pointed at a smaller one), so
+// every ancestor of v is smaller than v, no cycle can form, and the root is the smallest index
+// of the set.
+//
+// The union is Rem's algorithm: both paths are climbed together, always on the side whose parent
+// is the larger, that side's pointer is spliced over to the other path, and the climb ends when
+// the two parents agree or the larger side turns out to be a root, which is then hooked with one
+// compare-and-swap.  What matters on this chip: the root of the other -- smaller -- side is never
+// looked at.  With the usual find-then-link every find of the giant component (80 % of the 10^6
+// entries of config 2) ends with a load of its root's word to see that it is one; the words next
+// to it in its 64-byte line are hooked and spliced by atomics all the time, which keeps dropping
+// the line from every XCD's L2, and a single line served from the memory side takes ~90 requests
+// per microsecond: 0.23 to 2.1 ms for the pass, by how early the edge order lets the giant
+// component form.  Here a pair inside one tree ends on "parents agree", and a new entry is hooked
+// under whatever its partner points at.
+__device__ __forceinline__ uint32_t ld_parent(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_parent(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t u, uint32_t v)
+{
+    uint32_t pu = ld_parent(&parent[u]), pv = ld_parent(&parent[v]);
+    while (pu != pv) {
+        if (pu < pv) { // u is the side whose parent is the larger
+            uint32_t t = u; u = v; v = t;
+            t = pu; pu = pv; pv = t;
+        }
+        if (u == pu) { // a root, as far as was seen: under the other side's parent (pv < u)
+            const uint32_t old = atomicCAS(&parent[u], u, pv);
+            if (old == u) return;
+            pu = old; // hooked by somebody else meanwhile: that is where it points now
+        } else {
+            // Splice u over to the other path (never above what it points at by now: min) and go
+            // on from its old parent.  u's old tree is not cut off: this thread does not stop
+            // before that tree's root hangs under the other one, or the paths meet.
+            (void)__hip_atomic_fetch_min(&parent[u], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u = pu;
+            pu = ld_parent(&parent[u]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void uf_union_kernel(const uint2 *__restrict__ edges,
+                                                       const unsigned long long *counters,
+                                                       uint32_t edge_cap, uint32_t *parent)
+{
+    const unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const uint2 uv = edges[e];
+        if (uv.x & SYM_FLAG) uf_union(parent, uv.x & ~SYM_FLAG, uv.y);
+    }
+}
+
+// comp[v] = root of v (the smallest index of its set); lab[v] = v
+__global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint32_t *lab, uint32_t n)
+{
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        uint32_t r = ld_parent(&parent[v]);
+        if (r != v) {
+            for (;;) {
+                const uint32_t p = ld_parent(&parent[r]);
+                if (p == r) break;
+                r = p;
+            }
+            st_parent(&parent[v], r);
+        }
+        lab[v] = v;
+    }
+}
+
+// kept / root / survivor count of the entries of ranges (null: all n) from comp and lab:
+// label[v] = lab[comp[v]] (directional.rs:30-54,78-88), kept <=> label == v
+// (deduplicate_sam.rs:217-231)
+__global__ __launch_bounds__(256) void map_finalize_kernel(const uint32_t *__restrict__ comp,
+                                                           const uint32_t *__restrict__ lab,
+                                                           const RangeTask *__restrict__ ranges, uint32_t n,
+                                                           uint8_t *__restrict__ kept,
+                                                           uint32_t *__restrict__ root,
+                                                           unsigned long long *counters)
+{
+    unsigned int cnt = 0;
+    auto f = [&](uint32_t i) {
+        const uint32_t l = lab[comp[i]];
+        const bool kp = l == i;
+        kept[i] = kp ? 1 : 0;
+        if (root) root[i] = l;
+        cnt += kp ? 1u : 0u;
+    };
+    if (ranges) {
+        const RangeTask r = ranges[blockIdx.x];
+        for (uint32_t i = r.start + threadIdx.x; i < r.end; i += blockDim.x) f(i);
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) f(i);
+    }
+    block_count_add(cnt, &counters[CNT_KEPT]);
+}
+
+inline uint32_t grid_of(uint64_t work, int block, uint32_t cap)
+{
+    uint64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+} // namespace
+
+hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t n_edges_hint,
+                                hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    uf_union_kernel<<<grid_of(n_edges_hint, 256, 4096), 256, 0, s>>>(edges, counters, edge_cap, comp);
+    uf_flatten_kernel<<<grid_of(n, 256, 4096), 256, 0, s>>>(comp, lab, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
+                               uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
+                               unsigned long long *counters, hipStream_t s)
+{
+    if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
+    map_finalize_kernel<<<ranges ? n_ranges : grid_of(n, 1024, 1024), 256, 0, s>>>(comp, lab, ranges, n, kept,
+                                                                                    root, counters);
+    return hipGetLastError();
+}
+
+} // namespace umihip

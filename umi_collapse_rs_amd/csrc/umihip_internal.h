@@ -37,8 +37,15 @@ enum Counter : int {
     CNT_DIAG_ITEMS = 9, // ... and those on a bucket's diagonal (dense in hits; listed apart, worked off first)
     CNT_GRAB = 10,      // next item to hand out
     CNT_DIAG_GRAB = 11,
-    CNT_COUNT = 12,
+    CNT_SEG_TASKS = 12, // segment index: (sub-bucket, 64-row chunk) tasks its scan produced
+    CNT_SEG_PAIRS = 13, // ... and the pairs inside its sub-buckets (what the pair kernel compares)
+    CNT_KEPT_FUSED = 14, // survivors of the buckets the fused one-wave kernel finished by itself
+    CNT_COUNT = 16,
 };
+// The flags of the collapse rounds ("round r changed a label") sit behind the counters in the
+// same device block, so that one memset clears and one copy reads everything the host looks at.
+constexpr int MAX_ROUNDS_PER_SYNC = 16; // rounds enqueued between two host checks
+constexpr size_t CTRL_BYTES = CNT_COUNT * sizeof(unsigned long long) + (MAX_ROUNDS_PER_SYNC + 1) * sizeof(uint32_t);
 
 // Bit-sliced kernel: one block works on rows [bucket_start + 32*group0, ...) of one
 // bucket (256*G or 64*G groups of 32 rows, see BS_* below) against columns [col0, col1).
@@ -56,6 +63,50 @@ struct BsTask {
 // A run of entries for the per-entry kernels (prep, finalize): one block each.
 struct RangeTask {
     uint32_t start, end;
+    uint32_t seg; // segment (SegDesc index) of the bucket the run lies in, SEG_NONE if it has none
+};
+constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
+
+// ---- segment index: the n-gram partition of a large bucket ----------------------------------
+// Two UMIs within k substitutions agree exactly on at least one of k+1 disjoint base ranges
+// ("parts", pigeonhole).  A large bucket (a segment) is therefore cut k+1 times into
+// sub-buckets of entries that share a part's bases, and the all-pairs evaluation runs inside
+// the sub-buckets only: every pair within k is in one of them, every pair inside one is decided
+// by the same distance arithmetic as before.  The reference family's own n-gram index
+// (`--data ngram*` of the CLI, src/cli.rs:43-44, never implemented in the Rust port) prunes the
+// same way; the result is Naive's (src/data/naive.rs:26-40), which is all the reference ever runs.
+constexpr int SEG_MAX_PARTS = 8; // k + 1
+struct SegDesc {
+    uint32_t start, end;             // global entry range of the bucket
+    uint32_t bin_off[SEG_MAX_PARTS]; // first bin of part j in the call's bin array
+    uint8_t b0[SEG_MAX_PARTS];       // first base of part j
+    uint8_t nb[SEG_MAX_PARTS];       // leading bases of part j that index its bins (4^nb bins)
+    uint64_t mask[SEG_MAX_PARTS];    // filter-key bits those bases occupy: two entries share the bin of
+                                     // part j iff (key_a ^ key_b) & mask[j] == 0
+};
+// An entry in sub-bucket order: everything the pair kernel needs of it, 16 bytes
+struct SegRec32 {
+    uint32_t key; // filter key
+    uint32_t idx; // entry index
+    int32_t freq;
+    uint32_t pad;
+};
+struct SegRec64 {
+    uint64_t key;
+    uint32_t idx;
+    int32_t freq;
+};
+// One block of the bin scan: bins [bin0, bin0 + nbins) of part `part` of segment `seg`.
+struct SegScanChunk {
+    uint32_t bin0, nbins; // nbins <= SEG_SCAN_CHUNK
+    uint32_t seg, part;
+};
+constexpr uint32_t SEG_SCAN_CHUNK = 4096;
+// One unit of sub-bucket work: rows [row0, min(row0 + 64, end)) against the later entries of the
+// sub-bucket, columns (row, end), all positions in the sub-bucket arrays.
+struct SegTask {
+    uint32_t row0, end;
+    uint32_t seg, part;
 };
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
@@ -103,11 +154,60 @@ constexpr int SMALL_ROWS = SMALL_THREADS * SMALL_RPT;
 constexpr int BIG_ROWS = BIG_THREADS * BIG_RPT;
 constexpr int COL_TILE = 1024; // column keys staged in LDS per step
 
+// segs/bin_cnt (may be null): entries of ranges with a segment also count themselves into the
+// bins of their n_seg_parts parts
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label,
-                       unsigned long long *counters, hipStream_t s);
+                       unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
+                       uint32_t *bin_cnt, hipStream_t s);
+
+// ---- segment index (umihip_seg.hip) ----
+struct SegArgs {
+    const SegDesc *segs;
+    const SegScanChunk *chunks;
+    uint32_t n_chunks;
+    int n_parts;            // k + 1
+    uint32_t *bin_cnt;      // [n_bins] entries per bin (prep); reused as the scatter cursor
+    uint32_t *bin_start;    // [n_bins] first position of the bin in the sub-bucket arrays
+    uint2 *chunk_sums;      // [n_chunks] scratch of the scan: (entries, tasks) per chunk
+    SegTask *tasks;         // [task_cap]
+    uint32_t task_cap;
+    void *sub_rec;          // [n_parts * M] entries in sub-bucket order: SegRec32 / SegRec64, one
+                            // 16-byte store per entry and part
+    const RangeTask *ranges;
+    uint32_t n_ranges;
+    // the pair kernel's blocks leave what their edge stage still holds at the end in a slot of their
+    // own; seg_edge_append moves the slots to the edge list (no storm of atomics on the list's
+    // counter when all blocks finish together)
+    uint2 *priv_edges;      // [n_blocks * SEG_PRIV_CAP]
+    uint8_t *priv_dist;     // ... their distances (DataStruct mode), else null
+    uint32_t *priv_cnt;     // [n_blocks] entries in each slot, then (after the scan) their offsets
+    uint32_t dbg; // tuning experiments only (ctx option seg_dbg): 1 drop the queued hits, 2 skip the column loop
+};
+// exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];
+// then every entry of a segment is copied to its position in each part's sub-bucket order
+hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *freq, bool key32,
+                            unsigned long long *counters, hipStream_t s);
+constexpr uint32_t SEG_PRIV_CAP = 512; // = the LDS edge stage of a block
+// all pairs inside the sub-buckets: filter + exact check + edge emission (percentage: thresholds
+// are recomputed from the staged freq).  part/n_parts: a multi-GPU split takes every n_parts-th task.
+hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
+                            uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s);
+
+// ---- directional collapse by union-find (umihip_collapse.hip) ----
+// comp[] (= label[], identity on entry) becomes the smallest index of each entry's set under the
+// symmetric pairs; lab[] is initialised to the identity
+hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t n_edges_hint,
+                                hipStream_t s);
+// label = lab[comp[v]] for the entries of ranges (null: all n), kept / root / survivor count:
+// map_labels + finalize in one pass
+hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
+                               uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
+                               unsigned long long *counters, hipStream_t s);
+
 
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);
 

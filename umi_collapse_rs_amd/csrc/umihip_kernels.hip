@@ -19,50 +19,11 @@
 #include <utility>
 
 #include "umihip_internal.h"
+#include "umihip_device.h"
 
 namespace umihip {
 
 namespace {
-
-constexpr int CHECK_BLOCK = 32; // columns between two "any hit?" checks
-
-__device__ __forceinline__ int popc(uint32_t x) { return __builtin_popcount(x); }
-__device__ __forceinline__ int popc(uint64_t x) { return __builtin_popcountll(x); }
-
-// Padding keys for rows/columns past the end of a range.  They only have to be
-// unlikely to pass the filter: every hit is re-checked against the index range.
-template <typename KeyT> __device__ __forceinline__ KeyT pad_row();
-template <> __device__ __forceinline__ uint32_t pad_row<uint32_t>() { return 0xFFFFFFFFu; }
-template <> __device__ __forceinline__ uint64_t pad_row<uint64_t>() { return ~0ull; }
-template <typename KeyT> __device__ __forceinline__ KeyT pad_col();
-template <> __device__ __forceinline__ uint32_t pad_col<uint32_t>() { return 0x0F000000u; }
-template <> __device__ __forceinline__ uint64_t pad_col<uint64_t>() { return 0xF000000000000000ull; }
-
-// Rust `f32 as i32` (saturating, NaN -> 0) of percentage * (freq+1) as f32,
-// src/algo/directional.rs:38.
-__device__ __forceinline__ int32_t threshold_of(float percentage, int32_t freq)
-{
-    // freq + 1 wraps in a release build of the reference (Cargo.toml:16-19)
-    float prod = __fmul_rn(percentage, (float)(int32_t)((uint32_t)freq + 1u));
-    if (prod != prod) return 0;
-    if (prod >= 2147483648.0f) return 2147483647;
-    if (prod <= -2147483648.0f) return (-2147483647 - 1);
-    return (int32_t)prod;
-}
-
-// sum `cnt` over the block (256 threads) and add it to *dst with one atomic
-__device__ __forceinline__ void block_count_add(unsigned int cnt, unsigned long long *dst)
-{
-    __shared__ unsigned int part[4];
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int t = part[0] + part[1] + part[2] + part[3];
-        if (t) atomicAdd(dst, (unsigned long long)t);
-    }
-    __syncthreads(); // part[] may be reused by a second call
-}
 
 // Entry ranges a per-entry kernel works on: block b takes ranges[b] (<= RANGE_CHUNK entries);
 // ranges == nullptr: all n entries, grid-stride.  The fused small-bucket kernel validates,
@@ -87,9 +48,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
                                                    void *__restrict__ fkey,
                                                    int32_t *__restrict__ thr,
                                                    uint32_t *__restrict__ label,
-                                                   unsigned long long *__restrict__ counters)
+                                                   unsigned long long *__restrict__ counters,
+                                                   const SegDesc *__restrict__ segs, int n_seg_parts,
+                                                   uint32_t *__restrict__ bin_cnt)
 {
     unsigned int bad = 0, rises = 0;
+    // segment of this block's range (wave-uniform): its entries count themselves into the bins of
+    // the segment's parts (the histogram of the counting sort, umihip_seg.hip)
+    const uint32_t seg = ranges && segs ? ranges[blockIdx.x].seg : SEG_NONE;
+    const SegDesc *__restrict__ sd = seg != SEG_NONE ? segs + seg : nullptr;
     for_entries(ranges, n, [&](uint32_t i) {
         const uint64_t key = keys[i];
         const uint64_t nm = nmask ? nmask[i] : 0ull;
@@ -99,12 +66,19 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
         // filter key: N (100, masked by n_bits) folded onto A (000) so that the
         // filter distance never exceeds the exact one.
         const uint64_t k3 = key & ~nm;
+        uint32_t fk = 0;
         if (key32) {
-            uint32_t fk = 0;
             for (int b = 0; b < umi_len; b++) fk |= (uint32_t)((k3 >> (3 * b)) & 3ull) << (2 * b);
             ((uint32_t *)fkey)[i] = fk;
         } else {
             ((uint64_t *)fkey)[i] = k3;
+        }
+        if (sd) {
+            for (int j = 0; j < n_seg_parts; j++) {
+                const uint32_t v = key32 ? seg_part_bits(fk, sd->b0[j], sd->nb[j])
+                                         : seg_part_bits(k3, sd->b0[j], sd->nb[j]);
+                atomicAdd(&bin_cnt[sd->bin_off[j] + v], 1u);
+            }
         }
         // contract check: freq >= 1 and non-increasing inside a bucket.  A rise is legal only
         // at the first entry of a bucket: rises are counted here, rises at the starts of the
@@ -112,6 +86,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
         // (a per-entry search of the bucket table costs a chain of dependent loads in nearly
         // every wave).
         bad += f < 1 ? 1u : 0u;
+        // nmask == NULL promises that no key holds the N code (100): the kernels then take the
+        // filter key for the key.  A folded key has no base with bit 2 set and bits 0, 1 clear.
+        const uint64_t b2 = k3 & 0x4924924924924924ull;
+        bad += (b2 & ~((k3 << 1) | (k3 << 2))) != 0 ? 1u : 0u;
         rises += (i > 0 && f > freq[i - 1]) ? 1u : 0u;
     });
     block_count_add(bad, &counters[CNT_ERROR]);
@@ -131,113 +109,6 @@ __global__ __launch_bounds__(256) void bucket_rise_kernel(const int32_t *__restr
         if (s > 0 && s < e && e - s > fused_max) rises += freq[s] > freq[s - 1] ? 1u : 0u;
     }
     block_count_add(rises, &counters[CNT_START_RISES]);
-}
-
-// Edge list entries are (src, dst); SYM_FLAG on src marks a pair permitted in both
-// directions, stored once (entry indices stay below 2^31).
-constexpr uint32_t SYM_FLAG = 0x80000000u;
-
-// Per-block staging of emitted edges in LDS: one global atomic per flush instead of one
-// per edge (a single hot counter word saturates near 90 atomics/us on this chip).
-constexpr int EDGE_BUF = 512;
-struct EdgeStage {
-    uint2 e[EDGE_BUF];
-    uint8_t d[EDGE_BUF];
-    unsigned int count;      // edges staged (may run past EDGE_BUF: the excess went direct)
-    unsigned int candidates; // filter hits seen by this block
-    unsigned int base;       // flush: global position of e[0]
-};
-
-__device__ __forceinline__ void emit_edge(EdgeStage *st, uint2 *edges, uint8_t *edge_dist,
-                                          unsigned long long *counters, uint32_t edge_cap,
-                                          uint32_t u, uint32_t v, int dist, bool with_dist)
-{
-    const unsigned int slot = atomicAdd(&st->count, 1u);
-    if (slot < EDGE_BUF) {
-        st->e[slot] = make_uint2(u, v);
-        st->d[slot] = (uint8_t)dist;
-    } else { // stage full (a very dense tile): append directly
-        const unsigned long long pos = atomicAdd(&counters[CNT_EDGES], 1ull);
-        if (pos < edge_cap) {
-            edges[pos] = make_uint2(u, v);
-            if (with_dist) edge_dist[pos] = (uint8_t)dist;
-        }
-    }
-}
-
-// Exact check of one filter hit, with the reference's arithmetic, and edge emission.
-// Cold path (a few hits per million pairs): kept out of line, arguments by value so
-// that the kernel's argument block stays in SGPRs.
-__device__ __noinline__ void verify_pair(const uint64_t *__restrict__ keys,
-                                         const uint64_t *__restrict__ nmask,
-                                         const int32_t *__restrict__ freq,
-                                         const int32_t *__restrict__ thr, uint2 *edges,
-                                         uint8_t *edge_dist, unsigned long long *counters,
-                                         EdgeStage *st, uint32_t edge_cap, int k, int mode,
-                                         int32_t adj_max_freq, uint32_t row_end, uint32_t col1,
-                                         uint32_t gi, uint32_t gj, const uint32_t *perm)
-{
-    if (gi >= row_end || gj >= col1 || gi >= gj) return;
-    if (perm) { // prune mode: the tile lives in key-sorted order; back to entry indices
-        const uint32_t oi = perm[gi], oj = perm[gj];
-        gi = min(oi, oj);
-        gj = max(oi, oj);
-    }
-    atomicAdd(&st->candidates, 1u);
-    const uint64_t ka = keys[gi], kb = keys[gj];
-    const uint64_t na = nmask ? nmask[gi] : 0ull, nb = nmask ? nmask[gj] : 0ull;
-    const uint64_t x = na ^ nb;
-    // bitset.rs:85-87 (one word) and utils/mod.rs:25
-    const int bcx = __builtin_popcountll(x | (ka ^ kb)) - __builtin_popcountll(x) / 3;
-    const int dist = bcx / 2;
-    if (dist > k) return;
-    if (mode == MODE_NEIGHBOURS) {
-        emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, true);
-        return;
-    }
-    const int32_t fi = freq[gi], fj = freq[gj];
-    bool fwd, bwd;
-    if (mode == MODE_DIRECTIONAL) {
-        fwd = fj <= thr[gi]; // naive.rs:31 with max_freq = threshold(start) (directional.rs:38-39)
-        bwd = fi <= thr[gj];
-    } else {
-        fwd = fj <= adj_max_freq; // adjacency.rs:56
-        bwd = false;              // a root only ever sees entries of larger rank
-    }
-    if (fwd && bwd) // both directions permitted: one flagged entry, halves the list
-        emit_edge(st, edges, edge_dist, counters, edge_cap, gi | SYM_FLAG, gj, dist, false);
-    else if (fwd)
-        emit_edge(st, edges, edge_dist, counters, edge_cap, gi, gj, dist, false);
-    else if (bwd)
-        emit_edge(st, edges, edge_dist, counters, edge_cap, gj, gi, dist, false);
-}
-
-// Block-wide: move the staged edges to the global list.  Called by every thread.
-template <int THREADS>
-__device__ __forceinline__ void flush_edges(EdgeStage *st, uint2 *edges, uint8_t *edge_dist,
-                                            unsigned long long *counters, uint32_t edge_cap,
-                                            bool with_dist, bool final)
-{
-    __syncthreads();
-    const unsigned int n = min(st->count, (unsigned int)EDGE_BUF);
-    // Keep staging until the buffer is three quarters full: long runs of edges of one tile
-    // task stay together in the list, so the collapse's label gathers hit the same lines.
-    // (uniform: count is stable between the two barriers)
-    if (n == 0 || (!final && n < (unsigned int)(EDGE_BUF * 3 / 4))) return;
-    if (threadIdx.x == 0)
-        st->base = (unsigned int)min(atomicAdd(&counters[CNT_EDGES], (unsigned long long)n),
-                                     (unsigned long long)0xFFFFFFFFu);
-    __syncthreads();
-    const unsigned int base = st->base;
-    for (unsigned int i = threadIdx.x; i < n; i += THREADS) {
-        const unsigned long long pos = (unsigned long long)base + i;
-        if (pos < edge_cap) {
-            edges[pos] = st->e[i];
-            if (with_dist) edge_dist[pos] = st->d[i];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) st->count = 0;
 }
 
 // All pairs (row, col) of one task through the filter.  Each lane keeps RPT row
@@ -341,21 +212,6 @@ __device__ __forceinline__ uint32_t bit_of(uint64_t k3, int b)
 { // 64-bit filter keys keep the 3-bit layout: 2-bit code bit j of base i sits at 3i+j
     const int pos = 3 * (b >> 1) + (b & 1);
     return pos < 63 ? (uint32_t)(k3 >> pos) & 1u : 0u; // base 21 is padding (umi_len <= 21)
-}
-
-// Bases in which two filter keys differ (2-bit codes, N folded onto A: never above the exact
-// distance).  The unit-level filter lets through pairs that differ in two bases of one unit:
-// this count, from two neighbouring reads of the tile's own key array, drops them before the
-// exact check gathers keys, freq and thresholds through the permutation.
-__device__ __forceinline__ int filter_key_distance(uint32_t a, uint32_t b)
-{
-    const uint32_t x = a ^ b;
-    return __builtin_popcount((x | (x >> 1)) & 0x55555555u);
-}
-__device__ __forceinline__ int filter_key_distance(uint64_t a, uint64_t b)
-{ // 3 bits per base (the third is 0 in a folded key)
-    const uint64_t x = a ^ b;
-    return __builtin_popcountll((x | (x >> 1) | (x >> 2)) & 0x1249249249249249ull);
 }
 
 template <typename KeyT>
@@ -2114,7 +1970,7 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
         n_kept += c.kept;
     }
     block_count_add(bad, &counters[CNT_ERROR]);
-    block_count_add(n_kept, &counters[CNT_KEPT]);
+    block_count_add(n_kept, &counters[CNT_KEPT_FUSED]);
 }
 
 // ---- collapse: directed min-rank label propagation ---------------------------
@@ -2396,12 +2252,14 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label,
-                       unsigned long long *counters, hipStream_t s)
+                       unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
+                       uint32_t *bin_cnt, hipStream_t s)
 {
     if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
     prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
                                                                      percentage, key32 ? 1 : 0, fkey, thr,
-                                                                     label, counters);
+                                                                     label, counters, segs, n_seg_parts,
+                                                                     bin_cnt);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
                                                                      ranges ? fused_max : 0u, counters);
     return hipGetLastError();

@@ -1,0 +1,465 @@
+// Segment index of the large buckets (gfx950): the n-gram partition and the all-pairs evaluation
+// inside its sub-buckets.
+//
+// What it replaces in the reference (tkob-vh/umi-collapse-rs): the same rows of the scope table as
+// the tile kernels of umihip_kernels.hip -- Naive::remove_near's linear scans
+// (src/data/naive.rs:26-40) with BitSet::bit_count_xor / umi_dist (src/utils/bitset.rs:77-91,
+// src/utils/mod.rs:24-26) -- for buckets large enough that evaluating every pair is the cost.
+// Two UMIs within k substitutions agree exactly on at least one of k+1 disjoint base ranges, so a
+// bucket is cut k+1 times into sub-buckets by the value of one range (a counting sort on the
+// device: histogram in prep_kernel, scan, scatter) and only the pairs inside a sub-buckets are
+// evaluated, with the same arithmetic; a pair that shares several ranges is reported by the first.
+// Result = Naive's, pair for pair.  Integer/bitwise work, 64-lane waves, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "umihip_internal.h"
+#include "umihip_device.h"
+
+namespace umihip {
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = SEG_SCAN_CHUNK / SCAN_THREADS; // 16 bins per thread
+
+__device__ __forceinline__ uint32_t tasks_of_bin(uint32_t c)
+{
+    return c >= 2 ? (c - 1 + 63) / 64 : 0u; // the last entry of a sub-bucket has no later column
+}
+
+// (entries, tasks) per scan chunk
+__global__ __launch_bounds__(SCAN_THREADS) void seg_scan_reduce_kernel(SegArgs g)
+{
+    __shared__ uint32_t part_e[SCAN_THREADS / 64], part_t[SCAN_THREADS / 64];
+    const SegScanChunk ch = g.chunks[blockIdx.x];
+    uint32_t e = 0, t = 0;
+    for (uint32_t b = threadIdx.x; b < ch.nbins; b += SCAN_THREADS) {
+        const uint32_t c = g.bin_cnt[ch.bin0 + b];
+        e += c;
+        t += tasks_of_bin(c);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        e += __shfl_down(e, off);
+        t += __shfl_down(t, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part_e[threadIdx.x >> 6] = e;
+        part_t[threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t se = 0, st = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            se += part_e[w];
+            st += part_t[w];
+        }
+        g.chunk_sums[blockIdx.x] = make_uint2(se, st);
+    }
+}
+
+// exclusive scan of the chunk sums, in place (one block); totals to the counters
+__global__ __launch_bounds__(1024) void seg_scan_spine_kernel(SegArgs g, unsigned long long *counters)
+{
+    __shared__ uint2 wsum[16];
+    __shared__ uint2 carry;
+    if (threadIdx.x == 0) carry = make_uint2(0u, 0u);
+    __syncthreads();
+    for (uint32_t base = 0; base < g.n_chunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint2 v = i < g.n_chunks ? g.chunk_sums[i] : make_uint2(0u, 0u);
+        uint2 incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ux = __shfl_up(incl.x, d), uy = __shfl_up(incl.y, d);
+            if ((int)(threadIdx.x & 63) >= d) {
+                incl.x += ux;
+                incl.y += uy;
+            }
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint2 off = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) {
+            off.x += wsum[w].x;
+            off.y += wsum[w].y;
+        }
+        if (i < g.n_chunks) g.chunk_sums[i] = make_uint2(off.x + incl.x - v.x, off.y + incl.y - v.y);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = make_uint2(off.x + incl.x, off.y + incl.y);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[CNT_SEG_TASKS] = carry.y;
+}
+
+// bin_start, the task list, the pair count; bin_cnt is cleared for its second use as the
+// scatter cursor
+__global__ __launch_bounds__(SCAN_THREADS) void seg_scan_apply_kernel(SegArgs g, unsigned long long *counters)
+{
+    __shared__ uint2 wsum[SCAN_THREADS / 64];
+    const SegScanChunk ch = g.chunks[blockIdx.x];
+    const uint2 base = g.chunk_sums[blockIdx.x];
+    // a thread owns SCAN_PER_THREAD consecutive bins
+    uint32_t c[SCAN_PER_THREAD];
+    uint2 mine = make_uint2(0u, 0u);
+    const uint32_t b_first = threadIdx.x * SCAN_PER_THREAD;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER_THREAD; q++) {
+        const uint32_t b = b_first + q;
+        c[q] = b < ch.nbins ? g.bin_cnt[ch.bin0 + b] : 0u;
+        mine.x += c[q];
+        mine.y += tasks_of_bin(c[q]);
+    }
+    uint2 incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ux = __shfl_up(incl.x, d), uy = __shfl_up(incl.y, d);
+        if ((int)(threadIdx.x & 63) >= d) {
+            incl.x += ux;
+            incl.y += uy;
+        }
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint2 off = make_uint2(base.x + incl.x - mine.x, base.y + incl.y - mine.y);
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) {
+        off.x += wsum[w].x;
+        off.y += wsum[w].y;
+    }
+    unsigned long long pairs = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER_THREAD; q++) {
+        const uint32_t b = b_first + q;
+        if (b < ch.nbins) {
+            g.bin_start[ch.bin0 + b] = off.x;
+            g.bin_cnt[ch.bin0 + b] = 0;
+            const uint32_t nt = tasks_of_bin(c[q]);
+            for (uint32_t t = 0; t < nt; t++)
+                if (off.y + t < g.task_cap)
+                    g.tasks[off.y + t] = SegTask{off.x + 64u * t, off.x + c[q], ch.seg, ch.part};
+            pairs += (unsigned long long)c[q] * (c[q] ? c[q] - 1 : 0) / 2;
+            off.x += c[q];
+            off.y += nt;
+        }
+    }
+    // (64-bit sum over the block, one atomic)
+    __shared__ unsigned long long psum[SCAN_THREADS / 64];
+    for (int o = 32; o > 0; o >>= 1) pairs += __shfl_down(pairs, o);
+    if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = pairs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) t += psum[w];
+        if (t) atomicAdd(&counters[CNT_SEG_PAIRS], t);
+    }
+}
+
+template <typename KeyT> struct SegRecOf;
+template <> struct SegRecOf<uint32_t> { using type = SegRec32; };
+template <> struct SegRecOf<uint64_t> { using type = SegRec64; };
+__device__ __forceinline__ SegRec32 make_rec(uint32_t key, uint32_t idx, int32_t freq) { return SegRec32{key, idx, freq, 0u}; }
+__device__ __forceinline__ SegRec64 make_rec(uint64_t key, uint32_t idx, int32_t freq) { return SegRec64{key, idx, freq}; }
+
+// every entry of a segment to its position in each part's sub-bucket order (the order inside a
+// sub-bucket is arbitrary: all its pairs are evaluated, and a pair is reported with its entry
+// indices in rank order whatever the positions)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void seg_scatter_kernel(SegArgs g, const KeyT *__restrict__ fkey,
+                                                          const int32_t *__restrict__ freq)
+{
+    using Rec = typename SegRecOf<KeyT>::type;
+    const RangeTask r = g.ranges[blockIdx.x];
+    if (r.seg == SEG_NONE) return;
+    const SegDesc *__restrict__ sd = g.segs + r.seg;
+    Rec *__restrict__ sub = (Rec *)g.sub_rec;
+    for (uint32_t i = r.start + threadIdx.x; i < r.end; i += blockDim.x) {
+        const KeyT key = fkey[i];
+        const Rec rec = make_rec(key, i, freq[i]);
+        for (int j = 0; j < g.n_parts; j++) {
+            const uint32_t b = sd->bin_off[j] + seg_part_bits(key, sd->b0[j], sd->nb[j]);
+            const uint32_t pos = g.bin_start[b] + atomicAdd(&g.bin_cnt[b], 1u);
+            sub[pos] = rec;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t readlane_key(uint32_t v, int lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint64_t readlane_key(uint64_t v, int lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// base-level filter test of the inner loop: at most k bases of the two filter keys differ
+// (exact on N-free keys: the filter key is the key there)
+__device__ __forceinline__ bool within_k(uint32_t z, int k)
+{
+    return __builtin_popcount((z | (z >> 1)) & 0x55555555u) <= k;
+}
+__device__ __forceinline__ bool within_k(uint64_t z, int k)
+{ // 3-bit codes with the third bit clear: two codes differ in exactly two bits or in none
+    return __builtin_popcountll(z) <= 2 * k;
+}
+
+// All pairs inside the sub-buckets.  One wave per block, persistent over the task list.  A task
+// is 64 rows of a sub-bucket (one per lane, the filter key in a register) against the later
+// entries of the same sub-bucket, 64 columns at a time, one per lane as well: column j of the tile
+// is broadcast with v_readlane (j is a constant of the unrolled loop), and every lane keeps the
+// outcome for its own row as bit j of a 64-bit mask -- eight VALU instructions per column and 64
+// pairs (readlane, xor, shift, and-or, popcount, compare, select, or), no branch, no scalar
+// dependency, no LDS.  Sub-buckets are dense in neighbours by construction (about one pair in 200
+// at config 2: some twenty hits per 64 x 64 tile), so a hit must be cheap where it is found: after
+// the tile the lanes with a set bit note (row position, column position) in a queue in LDS, one
+// hit per lane and round.  When 64 are queued the wave works them off one per lane: both records
+// again (L2), the dedupe rule (a pair that shares an earlier part's bin was reported there), the
+// exact distance with the reference's arithmetic where keys carry N, the freq predicate of the
+// mode, and the edge goes to the block's LDS stage.
+template <typename KeyT, bool HAS_N>
+__global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, float percentage,
+                                                      uint32_t part, uint32_t n_parts)
+{
+    using Rec = typename SegRecOf<KeyT>::type;
+    constexpr uint32_t HITQ = 128; // a drain starts at 64 queued hits; one round adds at most 64
+    __shared__ EdgeStage stage;
+    __shared__ uint2 hitq[HITQ]; // (row position, column position) in the sub-bucket arrays
+    const int lane = threadIdx.x;
+    const Rec *__restrict__ sub = (const Rec *)g.sub_rec;
+    const uint4 *__restrict__ task_words = (const uint4 *)g.tasks;
+    const bool with_dist = a.mode == MODE_NEIGHBOURS;
+    if (lane == 0) {
+        stage.count = 0;
+        stage.candidates = 0;
+    }
+    __syncthreads();
+    const uint32_t n_tasks = (uint32_t)min((unsigned long long)g.task_cap, a.counters[CNT_SEG_TASKS]);
+    unsigned int n_cand = 0;
+    // masks of the bins of the parts before the task's own: a pair that shares one of them was
+    // reported there.  Kept while the tasks stay in one (segment, part): nearly always.
+    KeyT dup_mask[SEG_MAX_PARTS - 1];
+#pragma unroll
+    for (int j = 0; j < SEG_MAX_PARTS - 1; j++) dup_mask[j] = KeyT(0);
+    uint32_t have_seg = SEG_NONE, have_part = 0;
+    uint32_t nq = 0; // queued hits (wave-uniform); the queue outlives a task
+
+    // the queued hits, one per lane
+    auto drain = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        if (g.dbg & 1u) nq = 0;
+        for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t q = q0 + (uint32_t)lane;
+            if (q < nq) {
+                const uint2 h = hitq[q];
+                const Rec ra = sub[h.x], cb = sub[h.y];
+                const KeyT z = ra.key ^ cb.key;
+                bool ok = true;
+#pragma unroll
+                for (int p = 0; p < SEG_MAX_PARTS - 1; p++)
+                    ok = ok && (dup_mask[p] == KeyT(0) || (z & dup_mask[p]) != KeyT(0));
+                if (ok) {
+                    // entry indices in rank order (src/algo/directional.rs:67-72)
+                    const bool sw = cb.idx < ra.idx;
+                    const uint32_t gi = sw ? cb.idx : ra.idx, gj = sw ? ra.idx : cb.idx;
+                    const int32_t fi = sw ? cb.freq : ra.freq, fj = sw ? ra.freq : cb.freq;
+                    int dist;
+                    if (HAS_N) { // bitset.rs:85-87 (one word) and utils/mod.rs:25
+                        const uint64_t ka = a.keys[gi], kb = a.keys[gj];
+                        const uint64_t xn = a.nmask[gi] ^ a.nmask[gj];
+                        dist = (__builtin_popcountll(xn | (ka ^ kb)) - __builtin_popcountll(xn) / 3) / 2;
+                    } else { // no N in the call: the filter key is the key
+                        dist = filter_key_distance(ra.key, cb.key);
+                    }
+                    n_cand++;
+                    if (dist <= a.k && !(g.dbg & 4u)) {
+                        if (a.mode == MODE_NEIGHBOURS) {
+                            emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, true);
+                        } else {
+                            bool fwd, bwd;
+                            if (a.mode == MODE_DIRECTIONAL) { // naive.rs:31 under directional.rs:38-39
+                                fwd = fj <= threshold_of(percentage, fi);
+                                bwd = fi <= threshold_of(percentage, fj);
+                            } else { // adjacency.rs:56: a root only ever sees entries of larger rank
+                                fwd = fj <= a.adj_max_freq;
+                                bwd = false;
+                            }
+                            if (fwd && bwd)
+                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi | SYM_FLAG, gj, dist, false);
+                            else if (fwd)
+                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, false);
+                            else if (bwd)
+                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gj, gi, dist, false);
+                        }
+                    }
+                }
+            }
+        }
+        nq = 0;
+        __builtin_amdgcn_wave_barrier();
+        // (the stage is this wave's alone: its fill level is wave-uniform)
+        if ((unsigned int)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)&stage.count) >= (unsigned int)EDGE_BUF * 3u / 4u)
+            flush_edges<64>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, false);
+    };
+
+    // The loads run ahead of their use: the next task's record is fetched while this one is
+    // worked on, the next 64 columns while these are.
+    uint32_t t = blockIdx.x;
+    uint4 tw = t < n_tasks ? task_words[t] : make_uint4(0u, 0u, 0u, 0u);
+    while (t < n_tasks) {
+        const uint32_t t_next = t + gridDim.x;
+        const uint4 tw_next = t_next < n_tasks ? task_words[t_next] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t row0 = __builtin_amdgcn_readfirstlane(tw.x);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(tw.y);
+        const uint32_t seg = __builtin_amdgcn_readfirstlane(tw.z);
+        const uint32_t my_part = __builtin_amdgcn_readfirstlane(tw.w);
+        t = t_next;
+        tw = tw_next;
+        // A multi-GPU split hands out whole sub-buckets: the order inside one differs from rank to
+        // rank (the scatter's atomics), its extent does not -- `end` names the sub-bucket.
+        if (n_parts > 1 && (((end ^ (end >> 7)) * 0x9E3779B1u) >> 8) % n_parts != part) continue;
+        const uint32_t n_rows = min(64u, end - row0);
+        const uint32_t r = row0 + (uint32_t)lane;
+        KeyT x = pad_row<KeyT>();
+        if ((uint32_t)lane < n_rows) x = sub[r].key;
+        KeyT ky = pad_col<KeyT>();
+        if (row0 + 1 + (uint32_t)lane < end) ky = sub[row0 + 1 + (uint32_t)lane].key;
+        if (seg != have_seg || my_part != have_part) { // (wave-uniform)
+            if (nq) drain(); // the queued hits belong to the masks in hand
+            const SegDesc *__restrict__ sd = g.segs + seg;
+#pragma unroll
+            for (int j = 0; j < SEG_MAX_PARTS - 1; j++)
+                dup_mask[j] = (uint32_t)j < my_part ? (KeyT)sd->mask[j] : KeyT(0);
+            have_seg = seg;
+            have_part = my_part;
+        }
+
+        for (uint32_t c0 = row0 + 1; c0 < end; c0 += 64) {
+            // the next 64 columns, under way while these are walked
+            const uint32_t cn_pos = c0 + 64u + (uint32_t)lane;
+            KeyT kn = pad_col<KeyT>();
+            if (cn_pos < end) kn = sub[cn_pos].key;
+            const uint32_t nc = (g.dbg & 2u) ? 0u : min(64u, end - c0);
+            uint32_t hlo = 0, hhi = 0; // bit j: this lane's row is within k of column j of the tile
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                hlo |= within_k(x ^ readlane_key(ky, j), a.k) ? (1u << j) : 0u;
+            if (nc > 32) {
+#pragma unroll
+                for (int j = 0; j < 32; j++)
+                    hhi |= within_k(x ^ readlane_key(ky, 32 + j), a.k) ? (1u << j) : 0u;
+            }
+            unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
+            // the columns this lane's row may pair with: inside the tile, and behind the row
+            // (position c0 + j > r, i.e. j > lane - (c0 - row0))
+            const int j_min = lane + 1 - (int)(c0 - row0);
+            if (nc < 64) h &= (1ull << nc) - 1ull;
+            if (j_min > 0) h = j_min >= 64 ? 0ull : h & ~((1ull << j_min) - 1ull);
+            if ((uint32_t)lane >= n_rows) h = 0ull;
+            while (__any(h != 0ull)) { // one hit per lane and round
+                const unsigned long long bal = __ballot(h != 0ull);
+                if (h) {
+                    const int j = __builtin_ctzll(h);
+                    h &= h - 1ull;
+                    hitq[nq + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] =
+                        make_uint2(r, c0 + (uint32_t)j);
+                }
+                nq += (uint32_t)__builtin_popcountll(bal);
+                if (nq >= 64) drain();
+            }
+            ky = kn;
+        }
+    }
+    if (nq) drain();
+    { // what the stage still holds goes to this block's own slot (seg_edge_append_kernel moves it)
+        __builtin_amdgcn_wave_barrier();
+        const unsigned int left = min(*(volatile unsigned int *)&stage.count, (unsigned int)EDGE_BUF);
+        for (unsigned int i = lane; i < left; i += 64) {
+            g.priv_edges[(size_t)blockIdx.x * SEG_PRIV_CAP + i] = stage.e[i];
+            if (with_dist) g.priv_dist[(size_t)blockIdx.x * SEG_PRIV_CAP + i] = stage.d[i];
+        }
+        if (lane == 0) g.priv_cnt[blockIdx.x] = left;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_cand += __shfl_down(n_cand, off);
+    if (lane == 0 && n_cand) atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)n_cand);
+}
+
+// offsets of the blocks' slots behind what the list holds already (one block), the new total
+__global__ __launch_bounds__(1024) void seg_edge_scan_kernel(uint32_t *priv_cnt, uint32_t n_blocks,
+                                                             unsigned long long *counters)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const unsigned long long base = counters[CNT_EDGES];
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < n_blocks ? priv_cnt[i] : 0u;
+        uint32_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t off = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += wsum[w];
+        if (i < n_blocks) priv_cnt[i] = (uint32_t)min(base + off + incl - v, 0xFFFFFFFFull);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[CNT_EDGES] = base + carry;
+}
+
+__global__ __launch_bounds__(64) void seg_edge_move_kernel(SegArgs g, const uint32_t *__restrict__ priv_off,
+                                                           uint32_t n_blocks, uint2 *__restrict__ edges,
+                                                           uint8_t *__restrict__ edge_dist, uint32_t edge_cap,
+                                                           const unsigned long long *counters)
+{
+    const uint32_t b = blockIdx.x;
+    const unsigned long long first = priv_off[b];
+    const unsigned long long next = b + 1 < n_blocks ? (unsigned long long)priv_off[b + 1] : counters[CNT_EDGES];
+    const uint32_t cnt = (uint32_t)(next - first);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 64) {
+        const unsigned long long pos = first + i;
+        if (pos < edge_cap) {
+            edges[pos] = g.priv_edges[(size_t)b * SEG_PRIV_CAP + i];
+            if (edge_dist) edge_dist[pos] = g.priv_dist[(size_t)b * SEG_PRIV_CAP + i];
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *freq, bool key32,
+                            unsigned long long *counters, hipStream_t s)
+{
+    if (g.n_chunks == 0 || g.n_ranges == 0) return hipSuccess;
+    seg_scan_reduce_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g);
+    seg_scan_spine_kernel<<<1, 1024, 0, s>>>(g, counters);
+    seg_scan_apply_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g, counters);
+    if (key32) seg_scatter_kernel<uint32_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint32_t *)fkey, freq);
+    else seg_scatter_kernel<uint64_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint64_t *)fkey, freq);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
+                            uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s)
+{
+    if (g.n_chunks == 0 || n_blocks == 0) return hipSuccess;
+    const bool has_n = a.nmask != nullptr;
+    if (key32) {
+        if (has_n) seg_pair_kernel<uint32_t, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        else seg_pair_kernel<uint32_t, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+    } else {
+        if (has_n) seg_pair_kernel<uint64_t, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        else seg_pair_kernel<uint64_t, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+    }
+    seg_edge_scan_kernel<<<1, 1024, 0, s>>>(g.priv_cnt, n_blocks, a.counters);
+    seg_edge_move_kernel<<<n_blocks, 64, 0, s>>>(g, g.priv_cnt, n_blocks, a.edges,
+                                                 a.mode == MODE_NEIGHBOURS ? a.edge_dist : nullptr, a.edge_cap,
+                                                 a.counters);
+    return hipGetLastError();
+}
+
+} // namespace umihip
