@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libumihip.so")
+# (UMIHIP_LIB: tuning experiments load another build of the same library)
+LIB_PATH = os.environ.get("UMIHIP_LIB") or os.path.join(_HERE, "libumihip.so")
 
 UMI_OK = 0
 UMI_ERR_ARG, UMI_ERR_HIP, UMI_ERR_ORDER, UMI_ERR_NOMEM, UMI_ERR_NODEV, UMI_ERR_CHAR = (

@@ -22,17 +22,20 @@ namespace {
 // every ancestor of v is smaller than v, no cycle can form, and the root is the smallest index
 // of the set.
 //
-// The union is Rem's algorithm: both paths are climbed together, always on the side whose parent
-// is the larger, that side's pointer is spliced over to the other path, and the climb ends when
-// the two parents agree or the larger side turns out to be a root, which is then hooked with one
-// compare-and-swap.  What matters on this chip: the root of the other -- smaller -- side is never
-// looked at.  With the usual find-then-link every find of the giant component (80 % of the 10^6
-// entries of config 2) ends with a load of its root's word to see that it is one; the words next
-// to it in its 64-byte line are hooked and spliced by atomics all the time, which keeps dropping
-// the line from every XCD's L2, and a single line served from the memory side takes ~90 requests
-// per microsecond: 0.23 to 2.1 ms for the pass, by how early the edge order lets the giant
-// component form.  Here a pair inside one tree ends on "parents agree", and a new entry is hooked
-// under whatever its partner points at.
+// The union is Rem's algorithm without its splicing: both paths are climbed together, always on
+// the side whose parent is the larger, and the climb ends when the two parents agree or the larger
+// side turns out to be a root, which is then hooked with one compare-and-swap.  What matters on
+// this chip: the root of the other -- smaller -- side is never looked at.  With the usual
+// find-then-link every find of the giant component (80 % of the 10^6 entries of config 2) ends
+// with a load of its root's word to see that it is one; the words next to it in its 64-byte line
+// are hooked by atomics all the time, which keeps dropping the line from every XCD's L2, and a
+// single line served from the memory side takes ~90 requests per microsecond: 0.23 to 2.1 ms for
+// the pass, by how early the edge order lets the giant component form.  Here a pair inside one
+// tree ends on "parents agree", and a new entry is hooked under whatever its partner points at:
+// 0.15 ms whatever the order, about five scattered agent-scope accesses per pair at the
+// ~3e10 per second the chip serves.  Measured and dropped: splicing the climbed side over to the
+// other path (atomicMin: +0.03 ms, plain store: +0.07 ms -- the paths are short, the extra writes
+// are not free), ordinary loads instead of sc1 ones (no difference).
 __device__ __forceinline__ uint32_t ld_parent(const uint32_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -54,11 +57,7 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t u, uint32_t 
             const uint32_t old = atomicCAS(&parent[u], u, pv);
             if (old == u) return;
             pu = old; // hooked by somebody else meanwhile: that is where it points now
-        } else {
-            // Splice u over to the other path (never above what it points at by now: min) and go
-            // on from its old parent.  u's old tree is not cut off: this thread does not stop
-            // before that tree's root hangs under the other one, or the paths meet.
-            (void)__hip_atomic_fetch_min(&parent[u], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { // climb
             u = pu;
             pu = ld_parent(&parent[u]);
         }

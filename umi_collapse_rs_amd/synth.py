@@ -128,3 +128,29 @@ def config3(seed=3, n_reads=10_000_000, n_positions=100_000, umi_len=12, chunk=1
         offs.append(p["bucket_off"][1:] + base)
         base = base + p["bucket_off"][-1]
     return dict(keys=keys, freq=freq, bucket_off=np.concatenate(offs), n_reads=rpp * n_positions)
+
+
+def config2m(seed=22, n_reads=1_000_000, umi_len=12, n_molecules=100_000, err=0.01):
+    """One deep alignment position from the molecule model (SURVEY.md 8d's generator at one
+    position): n_molecules true UMIs uniform over ACGT^L, copies per molecule ~ 1 + Geometric
+    with mean n_reads / n_molecules (cut to exactly n_reads reads), every copy's UMI mutated per
+    base with probability err to one of the other three bases.  Unlike config 2's uniform UMIs the
+    unique UMIs come in clusters: a true UMI of high freq surrounded by its freq-1 error copies."""
+    rng = np.random.Generator(np.random.PCG64(int(splitmix64(seed, np.array([7], dtype=np.uint64))[0])))
+    mean = max(1.0, n_reads / n_molecules)
+    copies = rng.geometric(1.0 / mean, n_molecules).astype(np.int64)
+    csum = np.cumsum(copies)
+    if csum[-1] < n_reads:  # top up the last molecules
+        copies[-1] += n_reads - csum[-1]
+        csum = np.cumsum(copies)
+    mol_of = np.searchsorted(csum, np.arange(n_reads), side="right")
+    true = rng.integers(0, 4, (n_molecules, umi_len), dtype=np.uint8)
+    bases = true[mol_of]
+    mut = rng.random(bases.shape) < err
+    shift = rng.integers(1, 4, bases.shape, dtype=np.uint8)
+    bases = np.where(mut, (bases + shift) & 3, bases).astype(np.uint8)
+    bases = bases[rng.permutation(n_reads)]  # first-appearance order is not molecule order
+    st = stage(np.zeros(n_reads, dtype=np.int64), bases_to_keys(bases))
+    st["n_reads"] = n_reads
+    st["n_molecules"] = int(mol_of.max()) + 1
+    return st
