@@ -246,8 +246,9 @@ def main():
     d_kept = torch.zeros(n, dtype=torch.uint8, device=dev)
     boff = st["bucket_off"]
     max_n = max(sizes)
-    gather_in = torch.zeros(max_n, dtype=torch.uint8, device=dev)
-    gather_out = torch.zeros(max_n * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    # the kept mask travels as bits: ceil(n / 8) bytes per rank, padded to the largest slice
+    gather_in = torch.zeros((max_n + 7) // 8, dtype=torch.uint8, device=dev)
+    gather_out = torch.zeros(gather_in.numel() * world, dtype=torch.uint8, device=dev) if world > 1 else None
 
     ctx = umi.Context(dev_index, profile=True)
     opts = {}
@@ -270,8 +271,8 @@ def main():
         s = c.dedup_batch_device(d_keys.data_ptr(), 0, d_freq.data_ptr(), boff, args.umi_len,
                                  d_kept.data_ptr(), 0, k=args.k, percentage=args.p,
                                  stream=stream)
-        if world > 1:  # all-gatherv of the kept mask (padded all_gather over RCCL/xGMI)
-            gather_in[:n].copy_(d_kept)
+        if world > 1:  # all-gatherv of the kept mask: packed to bits on the device, padded all_gather
+            c.pack_mask_device(d_kept.data_ptr(), n, gather_in.data_ptr(), stream=stream)  # over RCCL/xGMI
             dist.all_gather_into_tensor(gather_out, gather_in)
         return s
 

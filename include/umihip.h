@@ -67,7 +67,24 @@ typedef struct umi_stats {
 
 /* ---- context ----------------------------------------------------------- */
 int umi_ctx_create(int device_id, umi_ctx **out);
+/* One context over several GPUs of the node (n_devices in 1..64; an id may repeat: two workers on
+ * one GPU).  umi_dedup_batch on it shards the call: independent buckets -- the iterations of
+ * src/deduplicate_sam.rs:207-233 share nothing but additive counters -- go to the devices by
+ * longest-processing-time on n_b^2, one host thread, stream and workspace per device, results
+ * scattered back at the buckets' own offsets (no exchange between devices); a call whose work is
+ * one giant bucket (>= "split_min" entries, more than half of the call's n_b^2) has that bucket's
+ * pair work split over the devices instead, the edge lists gathered on the first one and collapsed
+ * there.  Options set on it apply to every device.  The device-pointer entry points take a
+ * single-device context (a device pointer belongs to one device); umi_data_new uses the first
+ * device. */
+int umi_ctx_create_multi(const int *device_ids, int n_devices, umi_ctx **out);
+int umi_ctx_device_count(const umi_ctx *ctx); /* 1 for umi_ctx_create's, n_devices for the above */
 void umi_ctx_destroy(umi_ctx *ctx);
+/* The bucket -> rank assignment the multi-device context uses, for hosts that run one process per
+ * GPU: owner[b] in [0, n_ranks) for every bucket, deterministic (every rank computes the same
+ * table from bucket_off alone).  Host code, no GPU. */
+int umi_partition_buckets(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n_ranks,
+                          uint32_t *owner);
 /* Thread-local text of the last failure on this thread ("" if none). */
 const char *umi_last_error(void);
 /* Options: "profile" (0/1: record HIP events, fill ms_*), "edge_capacity"
@@ -94,7 +111,15 @@ const char *umi_last_error(void);
  * pairs followed by propagation along the one-way pairs; 0 = plain label propagation over all
  * pairs, one hop per round),
  * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
- * cannot hold a pair within k -- same result, fewer comparisons executed).
+ * cannot hold a pair within k -- same result, fewer comparisons executed),
+ * "seg_index" (0/1, default 1: buckets of at least "seg_min" entries, default 512, are cut into
+ * n-gram sub-buckets on the device -- two UMIs within k substitutions agree on one of k+1 base
+ * ranges -- and only the pairs inside a sub-bucket are evaluated; same result as the all-pairs
+ * tile kernels, which take those buckets when it is 0 or k + 1 parts would be shorter than 3
+ * bases; n_pairs_evaluated counts the pairs inside the sub-buckets), "seg_blocks" (one-wave
+ * blocks of its pair kernel, 0 = 24 per CU), "two_phase" values: 0 plain label propagation,
+ * 1 components of the symmetric pairs by hook/jump rounds then the one-way pairs, 2 (default)
+ * the components by union-find, "split_min" (multi-device contexts, see umi_ctx_create_multi).
  * Unknown name -> UMI_ERR_ARG. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
 /* 1 if this library was built with device code for gfx950 (always), for loaders */
@@ -138,6 +163,12 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                            uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
                            int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
                            void *hip_stream, umi_stats *stats);
+
+/* The kept mask as one bit per entry (bit i % 8 of byte i / 8; ceil(n / 8) bytes at d_bits), packed
+ * on the device and enqueued on hip_stream: what a one-process-per-GPU host all-gathers over RCCL
+ * to reassemble the mask of a bucket-sharded job (n / 8 bytes per rank instead of n). */
+int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_t *d_bits,
+                         void *hip_stream);
 
 /* ---- multi-GPU split of ONE call's all-pairs work (a single giant bucket
  *      does not shard by buckets).  Each of n_parts ranks holds the same inputs on its own

@@ -65,3 +65,20 @@ def test_no_cpu_fallback_without_gpu():
     src = "".join(open(os.path.join(ROOT, "umi_collapse_rs_amd", f)).read()
                   for f in ("__init__.py", "_lib.py", "api.py"))
     assert "oracle" not in src.replace("no CPU fallback", "")
+
+
+def test_multi_device_context_without_gpu_and_argument_errors():
+    import torch
+    L = umi.load()
+    h = C.c_void_p()
+    assert L.umi_ctx_create_multi(None, 2, C.byref(h)) == _lib.UMI_ERR_ARG
+    ids = (C.c_int * 2)(0, 0)
+    assert L.umi_ctx_create_multi(ids, 0, C.byref(h)) == _lib.UMI_ERR_ARG
+    assert L.umi_ctx_device_count(None) == 0
+    if not torch.cuda.is_available():
+        assert L.umi_ctx_create_multi(ids, 2, C.byref(h)) == _lib.UMI_ERR_NODEV  # no CPU fallback
+        assert not h.value
+    off = np.array([0, 5, 3], np.uint64)  # not monotone
+    owner = np.zeros(2, np.uint32)
+    assert L.umi_partition_buckets(_lib.ptr(off, C.c_uint64), 2, 2, _lib.ptr(owner, C.c_uint32)) == _lib.UMI_ERR_ARG
+    assert L.umi_partition_buckets(_lib.ptr(off, C.c_uint64), 2, 0, _lib.ptr(owner, C.c_uint32)) == _lib.UMI_ERR_ARG

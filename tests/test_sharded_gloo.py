@@ -89,3 +89,20 @@ def test_partition_is_deterministic_balanced_and_complete():
     keys = np.arange(int(off[-1]), dtype=np.uint64)
     k, _, f, loff, gidx = shard_arrays(keys, None, keys.astype(np.int32), off, parts[1])
     assert (k == gidx).all() and int(loff[-1]) == len(k)
+
+
+def test_library_partition_matches_the_python_reference():
+    """umi_partition_buckets (C++, what the multi-device context and the one-process-per-GPU hosts
+    use) against the exact-integer Python restatement of the same rule."""
+    from umi_collapse_rs_amd.api import partition_buckets as lib_partition
+    from umi_collapse_rs_amd.sharded import partition_buckets_py
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        nb = int(rng.integers(0, 400))
+        sizes = rng.integers(0, 50, nb) if trial % 3 else rng.integers(0, 3, nb) * rng.integers(1, 100000, nb)
+        if nb and trial % 4 == 0:
+            sizes[rng.integers(nb)] = 2_000_000_000  # n^2 near 2^62: the loads saturate, not wrap
+        off = np.zeros(nb + 1, np.uint64)
+        off[1:] = np.cumsum(sizes.astype(np.uint64))
+        for world in (1, 2, 3, 8, 64):
+            assert lib_partition(off, world).tolist() == partition_buckets_py(sizes, world).tolist(), (trial, world)

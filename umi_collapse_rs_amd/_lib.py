@@ -39,6 +39,9 @@ _u8p, _u32p, _u64p, _i32p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
 # name -> (restype, argtypes); every symbol include/umihip.h declares
 SIGNATURES = {
     "umi_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "umi_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "umi_ctx_device_count": (C.c_int, [C.c_void_p]),
+    "umi_partition_buckets": (C.c_int, [_u64p, C.c_uint64, C.c_uint32, _u32p]),
     "umi_ctx_destroy": (None, [C.c_void_p]),
     "umi_last_error": (C.c_char_p, []),
     "umi_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -51,6 +54,7 @@ SIGNATURES = {
                                          C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(Stats)]),
+    "umi_pack_mask_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "umi_pairs_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u64p,
                                            C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
                                            C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,

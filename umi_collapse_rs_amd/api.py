@@ -37,12 +37,28 @@ def to_bitset(umis, umi_len=None):
     return keys, nmask
 
 
+def partition_buckets(bucket_off, n_ranks):
+    """umi_partition_buckets: owner rank of every bucket (uint32[n_buckets]), the assignment the
+    multi-device context uses -- for hosts that run one process per GPU."""
+    bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+    nb = max(0, len(bucket_off) - 1)
+    owner = np.zeros(nb, dtype=np.uint32)
+    check(load().umi_partition_buckets(ptr(bucket_off, C.c_uint64), nb, n_ranks, ptr(owner, C.c_uint32)))
+    return owner
+
+
 class Context:
-    """One GPU context (umi_ctx).  One per process: one process per GPU."""
+    """One GPU context (umi_ctx): one per process in a one-process-per-GPU job; or, with a list
+    of device ids, one context over several GPUs of the node (umi_ctx_create_multi: dedup_batch
+    shards its buckets over them)."""
 
     def __init__(self, device_id=0, profile=False):
         self._h = C.c_void_p()
-        check(load().umi_ctx_create(device_id, C.byref(self._h)))
+        if isinstance(device_id, (list, tuple)):
+            ids = (C.c_int * len(device_id))(*[int(d) for d in device_id])
+            check(load().umi_ctx_create_multi(ids, len(device_id), C.byref(self._h)))
+        else:
+            check(load().umi_ctx_create(device_id, C.byref(self._h)))
         self.device_id = device_id
         if profile:
             self.set_option("profile", 1)
@@ -95,6 +111,10 @@ class Context:
                                             d_root or None, stream or None, C.byref(st)))
         return st.as_dict()
 
+
+    def pack_mask_device(self, d_kept, n, d_bits, stream=0):
+        """kept bytes -> bits on the device (umi_pack_mask_device), enqueued on `stream`."""
+        check(load().umi_pack_mask_device(self._h, d_kept, n, d_bits, stream or None))
 
     def pairs_partial_device(self, d_keys, d_nmask, d_freq, bucket_off, umi_len, part, n_parts,
                              d_edges, edge_capacity, k=1, percentage=0.5,

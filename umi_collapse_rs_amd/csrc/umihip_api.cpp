@@ -10,6 +10,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "umihip_internal.h"
@@ -113,6 +114,13 @@ struct PinnedBuf {
 } // namespace
 
 struct umi_ctx {
+    // a multi-device context (umi_ctx_create_multi) owns one ordinary context per device and has
+    // no device state of its own; an ordinary one has no subs
+    std::vector<umi_ctx *> subs;
+    // per-device staging of the sharded host-buffer call (pinned): this rank's entries gathered
+    // from the caller's arrays, its share of the bucket table, its results
+    PinnedBuf sh_in, sh_out;
+    std::vector<uint64_t> sh_boff;
     int device = 0;
     hipStream_t own_stream = nullptr;
     bool profile = false;
@@ -134,6 +142,8 @@ struct umi_ctx {
                        // pairs by hook/jump rounds, then the DAG; 2 the components by union-find
     bool seg_index = true;   // large buckets through the n-gram partition (umihip_seg.hip)
     uint32_t seg_min = 512;  // ... from this many entries up
+    uint64_t split_min = 200000; // multi-device: a bucket at least this large that dominates the call
+                                 // has its pairs split over the devices instead of the buckets
     uint32_t seg_dbg = 0;
     uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: 24 per CU, all resident at once)
     // workspace
@@ -1051,6 +1061,284 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
         .run(stats);
 }
 
+
+// ---- multi-device host-buffer call ------------------------------------------------------------
+// Buckets are independent (src/deduplicate_sam.rs:207-233 shares nothing between iterations but
+// additive counters), so a call shards with no exchange between the devices: every bucket goes to
+// one device (longest processing time first on n_b^2, partition_buckets_lpt), a host thread per
+// device gathers its buckets' entries into pinned staging, runs the ordinary pipeline on its
+// device's own stream and workspace, and scatters kept / root back to the caller's arrays at the
+// buckets' own offsets.  One giant bucket does not shard that way: then every device evaluates its
+// share of the bucket's sub-bucket tasks (umi_pairs_partial_device's path), the edge lists are
+// copied to the first device and collapsed there.
+struct ShardResult {
+    int rc = UMI_OK;
+    std::string err;
+    umi_stats st;
+};
+
+void merge_stats(umi_stats &a, const umi_stats &b)
+{
+    a.n_kept += b.n_kept;
+    a.n_pairs_evaluated += b.n_pairs_evaluated;
+    a.n_candidates += b.n_candidates;
+    a.n_edges += b.n_edges;
+    a.n_rounds = std::max(a.n_rounds, b.n_rounds);
+    a.n_pair_launches += b.n_pair_launches;
+    a.ms_total = std::max(a.ms_total, b.ms_total);
+    a.ms_prep = std::max(a.ms_prep, b.ms_prep);
+    a.ms_pairs = std::max(a.ms_pairs, b.ms_pairs);
+    a.ms_collapse = std::max(a.ms_collapse, b.ms_collapse);
+    a.ms_finalize = std::max(a.ms_finalize, b.ms_finalize);
+}
+
+int dedup_batch_single(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                       const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k, float percentage,
+                       int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root, umi_stats *stats);
+
+// one device's share of a bucket-sharded call (runs on its own host thread)
+void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *keys, const uint64_t *nmask,
+               const int32_t *freq, const uint64_t *bucket_off, int umi_len, int k, float percentage, int algo,
+               int32_t adj_max_freq, uint8_t *kept, uint32_t *root, ShardResult &res)
+{
+    memset(&res.st, 0, sizeof(res.st));
+    uint64_t n_local = 0;
+    sub->sh_boff.assign(1, 0);
+    for (uint64_t b : mine) {
+        n_local += bucket_off[b + 1] - bucket_off[b];
+        sub->sh_boff.push_back(n_local);
+    }
+    if (n_local == 0) return;
+    // pinned staging: keys | nmask | freq in, kept | root out
+    const size_t o_keys = 0, o_nmask = o_keys + n_local * 8, o_freq = o_nmask + (nmask ? n_local * 8 : 0);
+    const size_t in_bytes = o_freq + n_local * 4;
+    const size_t o_kept = 0, o_root = (n_local + 15) & ~(size_t)15, out_bytes = o_root + (root ? n_local * 4 : 0);
+    auto fail_here = [&](int rc) {
+        res.rc = rc;
+        res.err = umi_last_error(); // (this thread's message)
+    };
+    if (hipSetDevice(sub->device) != hipSuccess) {
+        res.rc = UMI_ERR_HIP;
+        res.err = "hipSetDevice failed on a worker thread";
+        return;
+    }
+    int rc;
+    if ((rc = sub->sh_in.reserve(in_bytes)) || (rc = sub->sh_out.reserve(out_bytes))) return fail_here(rc);
+    uint64_t at = 0;
+    for (uint64_t b : mine) {
+        const uint64_t s0 = bucket_off[b], len = bucket_off[b + 1] - s0;
+        memcpy(sub->sh_in.p + o_keys + at * 8, keys + s0, len * 8);
+        if (nmask) memcpy(sub->sh_in.p + o_nmask + at * 8, nmask + s0, len * 8);
+        memcpy(sub->sh_in.p + o_freq + at * 4, freq + s0, len * 4);
+        at += len;
+    }
+    umi_stats st;
+    rc = dedup_batch_single(sub, (const uint64_t *)(sub->sh_in.p + o_keys),
+                            nmask ? (const uint64_t *)(sub->sh_in.p + o_nmask) : nullptr,
+                            (const int32_t *)(sub->sh_in.p + o_freq), sub->sh_boff.data(), mine.size(), umi_len, k,
+                            percentage, algo, adj_max_freq, (uint8_t *)(sub->sh_out.p + o_kept),
+                            root ? (uint32_t *)(sub->sh_out.p + o_root) : nullptr, &st);
+    if (rc) return fail_here(rc);
+    res.st = st;
+    // back to the caller's index space: a bucket's entries keep their order, a root index moves
+    // with its bucket
+    at = 0;
+    for (uint64_t b : mine) {
+        const uint64_t s0 = bucket_off[b], len = bucket_off[b + 1] - s0;
+        memcpy(kept + s0, sub->sh_out.p + o_kept + at, len);
+        if (root) {
+            const uint32_t *src = (const uint32_t *)(sub->sh_out.p + o_root) + at;
+            const uint32_t shift = (uint32_t)(s0 - at); // (mod 2^32: local index + shift = global index)
+            for (uint64_t i = 0; i < len; i++) root[s0 + i] = src[i] + shift;
+        }
+        at += len;
+    }
+}
+
+// the multi-device split of a call whose work is one giant bucket
+int dedup_batch_split(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                      const uint64_t *bucket_off, uint64_t n_buckets, uint64_t n, int umi_len, int k,
+                      float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
+                      umi_stats *stats)
+{
+    const uint32_t n_dev = (uint32_t)ctx->subs.size();
+    const int mode = algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY;
+    std::vector<ShardResult> res(n_dev);
+    std::vector<uint64_t> n_edges(n_dev, 0);
+    std::vector<std::thread> pool;
+    for (uint32_t r = 0; r < n_dev; r++)
+        pool.emplace_back([&, r] {
+            umi_ctx *sub = ctx->subs[r];
+            ShardResult &out = res[r];
+            auto fail_here = [&](int rc) {
+                out.rc = rc;
+                out.err = umi_last_error();
+            };
+            memset(&out.st, 0, sizeof(out.st));
+            if (hipSetDevice(sub->device) != hipSuccess) {
+                out.rc = UMI_ERR_HIP;
+                out.err = "hipSetDevice failed on a worker thread";
+                return;
+            }
+            int rc;
+            if ((rc = sub->in_keys.reserve(n * 8)) || (rc = sub->in_freq.reserve(n * 4)) ||
+                (nmask && (rc = sub->in_nmask.reserve(n * 8))))
+                return fail_here(rc);
+            hipStream_t s = sub->own_stream;
+            hipError_t e = hipMemcpyAsync(sub->in_keys.p, keys, n * 8, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(sub->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && nmask) e = hipMemcpyAsync(sub->in_nmask.p, nmask, n * 8, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) {
+                out.rc = UMI_ERR_HIP;
+                out.err = std::string("upload failed: ") + hipGetErrorString(e);
+                return;
+            }
+            Pipeline p(sub, sub->in_keys.as<uint64_t>(), nmask ? sub->in_nmask.as<uint64_t>() : nullptr,
+                       sub->in_freq.as<int32_t>(), bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage, mode,
+                       adj_max_freq, nullptr, nullptr, s, r, n_dev);
+            if ((rc = p.run(&out.st))) return fail_here(rc);
+            n_edges[r] = p.edge_count();
+        });
+    for (auto &t : pool) t.join();
+    for (uint32_t r = 0; r < n_dev; r++)
+        if (res[r].rc) return fail(res[r].rc, "device %d: %s", ctx->subs[r]->device, res[r].err.c_str());
+    // the edge lists to the first device (peer copy, or through the host where peers cannot see
+    // each other), the collapse there
+    umi_ctx *c0 = ctx->subs[0];
+    uint64_t total = 0;
+    for (uint64_t e : n_edges) total += e;
+    if (total >= 0x7FFFFFF0ull) return fail(UMI_ERR_NOMEM, "gathered edge list too large");
+    HIP_TRY(hipSetDevice(c0->device));
+    int rc;
+    if ((rc = c0->out_kept.reserve(n)) || (rc = c0->out_root.reserve(n * 4))) return rc;
+    DevBuf gathered;
+    if ((rc = gathered.reserve(std::max<uint64_t>(total, 1) * sizeof(uint2)))) return rc;
+    uint64_t at = 0;
+    hipError_t e = hipSuccess;
+    for (uint32_t r = 0; r < n_dev && e == hipSuccess; r++) {
+        if (!n_edges[r]) continue;
+        e = hipMemcpy((char *)gathered.p + at * sizeof(uint2), ctx->subs[r]->edges.p, n_edges[r] * sizeof(uint2),
+                      hipMemcpyDefault);
+        at += n_edges[r];
+    }
+    if (e != hipSuccess) {
+        gathered.release();
+        return fail(UMI_ERR_HIP, "edge gather failed: %s", hipGetErrorString(e));
+    }
+    umi_stats st;
+    memset(&st, 0, sizeof(st));
+    rc = EdgeCollapse(c0, (uint32_t)n, gathered.as<uint2>(), (uint32_t)total, mode, c0->out_kept.as<uint8_t>(),
+                      root ? c0->out_root.as<uint32_t>() : nullptr, c0->own_stream)
+             .run(&st);
+    if (rc == UMI_OK) {
+        e = hipMemcpy(kept, c0->out_kept.p, n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && root) e = hipMemcpy(root, c0->out_root.p, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(UMI_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+    }
+    gathered.release();
+    if (rc) return rc;
+    if (stats) {
+        umi_stats total_st = res[0].st;
+        for (uint32_t r = 1; r < n_dev; r++) merge_stats(total_st, res[r].st);
+        total_st.n_umis = n;
+        total_st.n_buckets = n_buckets;
+        total_st.max_bucket = res[0].st.max_bucket;
+        total_st.n_pairs = res[0].st.n_pairs;
+        total_st.n_kept = st.n_kept;
+        total_st.n_edges = total;
+        total_st.n_rounds = st.n_rounds;
+        *stats = total_st;
+    }
+    return UMI_OK;
+}
+
+int dedup_batch_multi(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                      const uint64_t *bucket_off, uint64_t n_buckets, uint64_t n, int umi_len, int k,
+                      float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
+                      umi_stats *stats)
+{
+    const uint32_t n_dev = (uint32_t)ctx->subs.size();
+    // one bucket with more than half of the call's n_b^2: its pairs are split, not the buckets
+    // (only where pairs are evaluated at all: the reference's adjacency needs none)
+    long double cost = 0, top = 0;
+    uint64_t max_bucket = 0;
+    for (uint64_t b = 0; b < n_buckets; b++) {
+        const long double sz = (long double)(bucket_off[b + 1] - bucket_off[b]);
+        cost += sz * sz;
+        top = std::max(top, sz * sz);
+        max_bucket = std::max<uint64_t>(max_bucket, (uint64_t)sz);
+    }
+    const bool need_pairs = !(algo == UMI_ALGO_ADJACENCY && adj_max_freq < 1);
+    if (n_dev > 1 && need_pairs && max_bucket >= ctx->split_min && top * 2 > cost)
+        return dedup_batch_split(ctx, keys, nmask, freq, bucket_off, n_buckets, n, umi_len, k, percentage, algo,
+                                 adj_max_freq, kept, root, stats);
+    std::vector<uint32_t> owner;
+    partition_buckets_lpt(bucket_off, n_buckets, n_dev, owner);
+    std::vector<std::vector<uint64_t>> mine(n_dev);
+    for (uint64_t b = 0; b < n_buckets; b++) mine[owner[b]].push_back(b);
+    std::vector<ShardResult> res(n_dev);
+    std::vector<std::thread> pool;
+    for (uint32_t r = 0; r < n_dev; r++)
+        pool.emplace_back([&, r] {
+            run_shard(ctx->subs[r], mine[r], keys, nmask, freq, bucket_off, umi_len, k, percentage, algo, adj_max_freq,
+                      kept, root, res[r]);
+        });
+    for (auto &t : pool) t.join();
+    for (uint32_t r = 0; r < n_dev; r++)
+        if (res[r].rc) return fail(res[r].rc, "device %d: %s", ctx->subs[r]->device, res[r].err.c_str());
+    if (stats) {
+        umi_stats total = res[0].st;
+        for (uint32_t r = 1; r < n_dev; r++) {
+            merge_stats(total, res[r].st);
+            total.max_bucket = std::max(total.max_bucket, res[r].st.max_bucket);
+            total.n_pairs += res[r].st.n_pairs;
+        }
+        total.n_umis = n;
+        total.n_buckets = n_buckets;
+        *stats = total;
+    }
+    return UMI_OK;
+}
+
+int dedup_batch_single(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
+                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
+                    umi_stats *stats)
+{
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    if (rc) return rc;
+    if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    if (n == 0) {
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->n_buckets = n_buckets;
+        }
+        return UMI_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in_keys.reserve(n * 8)) || (rc = ctx->in_freq.reserve(n * 4)) ||
+        (rc = ctx->out_kept.reserve(n)) || (rc = ctx->out_root.reserve(n * 4)))
+        return rc;
+    if (nmask && (rc = ctx->in_nmask.reserve(n * 8))) return rc;
+    hipStream_t s = ctx->own_stream;
+    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
+    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, n * 8, hipMemcpyHostToDevice, s));
+    rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
+                      nmask ? ctx->in_nmask.as<uint64_t>() : nullptr, ctx->in_freq.as<int32_t>(),
+                      bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
+                      algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
+                      adj_max_freq, ctx->out_kept.as<uint8_t>(),
+                      root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
+    if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return UMI_OK;
+}
+
+
 } // namespace
 
 extern "C" {
@@ -1095,7 +1383,14 @@ int umi_ctx_create(int device_id, umi_ctx **out)
 void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
+    if (!ctx->subs.empty()) { // a multi-device context: nothing of its own on a device
+        for (umi_ctx *sub : ctx->subs) umi_ctx_destroy(sub);
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
+    ctx->sh_in.release();
+    ctx->sh_out.release();
     DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->plan_tables, &ctx->fkey_sorted, &ctx->perm,
                       &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_chunk_sums, &ctx->seg_tasks,
                       &ctx->seg_sub_rec, &ctx->seg_priv_edges, &ctx->seg_priv_dist, &ctx->seg_priv_cnt,
@@ -1118,6 +1413,18 @@ void umi_ctx_destroy(umi_ctx *ctx)
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return fail(UMI_ERR_ARG, "ctx/name is NULL");
+    if (!strcmp(name, "split_min")) {
+        if (value < 2) return fail(UMI_ERR_ARG, "split_min must be >= 2");
+        ctx->split_min = (uint64_t)value;
+        return UMI_OK;
+    }
+    if (!ctx->subs.empty()) { // every device of a multi-device context
+        for (umi_ctx *sub : ctx->subs) {
+            const int rc = umi_ctx_set_option(sub, name, value);
+            if (rc) return rc;
+        }
+        return UMI_OK;
+    }
     if (!strcmp(name, "profile")) {
         ctx->profile = value != 0;
     } else if (!strcmp(name, "edge_capacity")) {
@@ -1177,6 +1484,87 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     return UMI_OK;
 }
 
+int umi_ctx_create_multi(const int *device_ids, int n_devices, umi_ctx **out)
+{
+    if (!out) return fail(UMI_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64)
+        return fail(UMI_ERR_ARG, "device_ids is NULL or n_devices outside 1..64");
+    umi_ctx *ctx = new (std::nothrow) umi_ctx();
+    if (!ctx) return fail(UMI_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; i++) {
+        umi_ctx *sub = nullptr;
+        const int rc = umi_ctx_create(device_ids[i], &sub);
+        if (rc) {
+            const std::string msg = umi_last_error();
+            umi_ctx_destroy(ctx);
+            return fail(rc, "%s", msg.c_str());
+        }
+        ctx->subs.push_back(sub);
+    }
+    ctx->device = device_ids[0];
+    *out = ctx;
+    return UMI_OK;
+}
+
+int umi_ctx_device_count(const umi_ctx *ctx) { return !ctx ? 0 : (ctx->subs.empty() ? 1 : (int)ctx->subs.size()); }
+
+int umi_partition_buckets(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n_ranks, uint32_t *owner)
+{
+    if (!bucket_off || (!owner && n_buckets)) return fail(UMI_ERR_ARG, "bucket_off/owner is NULL");
+    if (n_ranks < 1) return fail(UMI_ERR_ARG, "n_ranks must be >= 1");
+    for (uint64_t b = 0; b < n_buckets; b++)
+        if (bucket_off[b + 1] < bucket_off[b]) return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
+    std::vector<uint32_t> o;
+    partition_buckets_lpt(bucket_off, n_buckets, n_ranks, o);
+    for (uint64_t b = 0; b < n_buckets; b++) owner[b] = o[b];
+    return UMI_OK;
+}
+
+int umi_dedup_batch(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
+                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
+                    umi_stats *stats)
+{
+    if (ctx && !ctx->subs.empty()) {
+        uint64_t n = 0;
+        int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+        if (rc) return rc;
+        if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+        for (uint64_t b = 0; b < n_buckets; b++)
+            if (bucket_off[b + 1] < bucket_off[b])
+                return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
+        if (n == 0) {
+            if (stats) {
+                memset(stats, 0, sizeof(*stats));
+                stats->n_buckets = n_buckets;
+            }
+            return UMI_OK;
+        }
+        if (ctx->subs.size() == 1)
+            return dedup_batch_single(ctx->subs[0], keys, nmask, freq, bucket_off, n_buckets, umi_len, k, percentage,
+                                      algo, adj_max_freq, kept, root, stats);
+        return dedup_batch_multi(ctx, keys, nmask, freq, bucket_off, n_buckets, n, umi_len, k, percentage, algo,
+                                 adj_max_freq, kept, root, stats);
+    }
+    return dedup_batch_single(ctx, keys, nmask, freq, bucket_off, n_buckets, umi_len, k, percentage, algo,
+                              adj_max_freq, kept, root, stats);
+}
+
+int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_t *d_bits, void *hip_stream)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
+    if (n && (!d_kept || !d_bits)) return fail(UMI_ERR_ARG, "kept/bits is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_pack_mask(d_kept, n, d_bits, (hipStream_t)hip_stream));
+    return UMI_OK;
+}
+
 int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys, uint64_t *nmask)
 {
     if ((!ascii && n) || !keys) return fail(UMI_ERR_ARG, "ascii/keys is NULL");
@@ -1208,6 +1596,11 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                            int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
                            uint8_t *d_kept, uint32_t *d_root, void *hip_stream, umi_stats *stats)
 {
+    if (ctx && !ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
     uint64_t n = 0;
     int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
     if (rc) return rc;
@@ -1232,6 +1625,11 @@ int umi_pairs_partial_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_
                              uint64_t edge_capacity, uint64_t *n_edges_out, void *hip_stream,
                              umi_stats *stats)
 {
+    if (ctx && !ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
     uint64_t n = 0;
     int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
     if (rc) return rc;
@@ -1264,6 +1662,11 @@ int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges,
                               umi_stats *stats)
 {
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
     if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
         return fail(UMI_ERR_ARG, "unknown algo %d", algo);
     if (n >= 0x7FFFFFF0ull || n_edges >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "too many entries/edges");
@@ -1273,44 +1676,6 @@ int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY, d_kept,
                         d_root, (hipStream_t)hip_stream)
         .run(stats);
-}
-
-int umi_dedup_batch(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
-                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
-                    umi_stats *stats)
-{
-    uint64_t n = 0;
-    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
-    if (rc) return rc;
-    if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
-    if (n == 0) {
-        if (stats) {
-            memset(stats, 0, sizeof(*stats));
-            stats->n_buckets = n_buckets;
-        }
-        return UMI_OK;
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    if ((rc = ctx->in_keys.reserve(n * 8)) || (rc = ctx->in_freq.reserve(n * 4)) ||
-        (rc = ctx->out_kept.reserve(n)) || (rc = ctx->out_root.reserve(n * 4)))
-        return rc;
-    if (nmask && (rc = ctx->in_nmask.reserve(n * 8))) return rc;
-    hipStream_t s = ctx->own_stream;
-    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
-    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, n * 8, hipMemcpyHostToDevice, s));
-    rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
-                      nmask ? ctx->in_nmask.as<uint64_t>() : nullptr, ctx->in_freq.as<int32_t>(),
-                      bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
-                      algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
-                      adj_max_freq, ctx->out_kept.as<uint8_t>(),
-                      root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
-    if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return UMI_OK;
 }
 
 } // extern "C"
@@ -1336,6 +1701,7 @@ int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, cons
     if (!out) return fail(UMI_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) ctx = ctx->subs[0]; // one bucket's store lives on one device
     if (n && (!keys || !freq)) return fail(UMI_ERR_ARG, "keys/freq is NULL");
     if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
         return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);

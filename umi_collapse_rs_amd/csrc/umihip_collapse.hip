@@ -120,6 +120,19 @@ __global__ __launch_bounds__(256) void map_finalize_kernel(const uint32_t *__res
     block_count_add(cnt, &counters[CNT_KEPT]);
 }
 
+// kept[] (one byte per entry) as one bit per entry, little-endian inside a byte: a wave packs 64
+// entries with one ballot (the multi-GPU gather moves n / 8 bytes instead of n)
+__global__ __launch_bounds__(256) void pack_mask_kernel(const uint8_t *__restrict__ kept, uint64_t n,
+                                                        uint8_t *__restrict__ bits)
+{
+    const uint64_t n_round = (n + 63) & ~63ull; // (whole waves: the ballot needs every lane)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long bal = __ballot(i < n && kept[i] != 0);
+        const uint32_t lane = threadIdx.x & 63;
+        if (lane < 8 && (i - lane) + 8ull * lane < n) bits[((i - lane) >> 3) + lane] = (uint8_t)(bal >> (8 * lane));
+    }
+}
+
 inline uint32_t grid_of(uint64_t work, int block, uint32_t cap)
 {
     uint64_t g = (work + block - 1) / block;
@@ -137,6 +150,13 @@ hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *co
     if (n == 0) return hipSuccess;
     uf_union_kernel<<<grid_of(n_edges_hint, 256, 4096), 256, 0, s>>>(edges, counters, edge_cap, comp);
     uf_flatten_kernel<<<grid_of(n, 256, 4096), 256, 0, s>>>(comp, lab, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    pack_mask_kernel<<<grid_of(n, 256, 2048), 256, 0, s>>>(kept, n, bits);
     return hipGetLastError();
 }
 

@@ -204,6 +204,8 @@ hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *co
                                 hipStream_t s);
 // label = lab[comp[v]] for the entries of ranges (null: all n), kept / root / survivor count:
 // map_labels + finalize in one pass
+// bits[i / 8] bit (i % 8) = kept[i] != 0, for i < n (ceil(n / 8) bytes written)
+hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipStream_t s);
 hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
                                uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
                                unsigned long long *counters, hipStream_t s);

@@ -70,6 +70,11 @@ using UmiFreqMap = std::vector<std::pair<const BitSet *, int32_t>>;
 class Context {
   public:
     explicit Context(int device_id = 0) { check(umi_ctx_create(device_id, &h_)); }
+    // several GPUs of the node: dedup_batch shards its buckets over them (umi_ctx_create_multi)
+    explicit Context(const std::vector<int> &device_ids)
+    {
+        check(umi_ctx_create_multi(device_ids.data(), (int)device_ids.size(), &h_));
+    }
     ~Context() { umi_ctx_destroy(h_); }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;

@@ -42,7 +42,7 @@ struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
     // development switches (not in the reference)
     std::string dump_staging; // write the staged hot-path input here and stop before the GPU
     bool passthrough = false; // write every mapped record back (codec round trip), no dedup
-    int device = 0;
+    std::vector<int> devices{0}; // --device <ID> or --devices <ID,ID,...>
 };
 
 [[noreturn]] void die(const std::string &msg)
@@ -72,7 +72,8 @@ void usage()
               "      --tag                Write every read tagged with its cluster (MI, cs, su) instead of\n"
               "                           removing duplicates\n"
               "      --two-pass           accepted and rejected (see header)\n"
-              "      --device <ID>        GPU to use [default: 0]");
+              "      --device <ID>        GPU to use [default: 0]\n"
+              "      --devices <ID,..>    several GPUs of the node: alignment positions are sharded over them");
 }
 
 Cli parse(int argc, char **argv)
@@ -103,7 +104,17 @@ Cli parse(int argc, char **argv)
         else if (a == "--tag") c.track_clusters = true;
         else if (a == "--dump-staging") c.dump_staging = need(i);
         else if (a == "--passthrough") c.passthrough = true;
-        else if (a == "--device") c.device = std::atoi(need(i));
+        else if (a == "--device") c.devices.assign(1, std::atoi(need(i)));
+        else if (a == "--devices") { // the GPUs of the node the position buckets are sharded over
+            c.devices.clear();
+            std::string list = need(i);
+            for (size_t p = 0; p <= list.size();) {
+                const size_t q = std::min(list.find(',', p), list.size());
+                if (q == p) die("--devices wants a comma separated list of GPU ids");
+                c.devices.push_back(std::atoi(list.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+        }
         else if (a == "-h" || a == "--help") { usage(); std::exit(0); }
         else die("unexpected argument '" + a + "'");
     }
@@ -385,7 +396,7 @@ int main(int argc, char **argv)
         double t_gpu0 = now_s(), t_gpu1 = t_gpu0;
         if (!args.passthrough && n) {
             umi_ctx *ctx = nullptr;
-            if (umi_ctx_create(args.device, &ctx) != UMI_OK) die(umi_last_error());
+            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) die(umi_last_error());
             // The reference accepts every --data value and always runs Naive
             // (deduplicate_sam.rs:210-213), so the result is the same for all of them.  Here
             // "naive" is the plain all-pairs tile walk; any other value (the default is

@@ -9,21 +9,35 @@ import heapq
 
 import numpy as np
 
+from ._lib import UMI_ERR_NOMEM, UmiHipError
 
-def partition_buckets(sizes, world_size):
-    """Longest-processing-time assignment on cost n_b^2 (ties -> lower bucket index,
-    then lower rank).  Returns a list of ascending bucket-index arrays, one per rank.
-    Deterministic: every rank computes the same answer from the same sizes."""
-    sizes = np.asarray(sizes, dtype=np.int64)
-    cost = sizes.astype(np.float64) ** 2 + sizes  # + n: empty-ish buckets still cost a pass
-    order = np.lexsort((np.arange(len(sizes)), -cost))
-    heap = [(0.0, r) for r in range(world_size)]
+
+def partition_buckets_py(sizes, world_size):
+    """Longest-processing-time assignment on cost n_b^2 + n_b (ties -> lower bucket index,
+    then lower rank), in exact integer arithmetic: the reference implementation the library's
+    umi_partition_buckets is checked against.  Returns the owner rank of every bucket."""
+    sizes = [int(x) for x in sizes]
+    cost = [x * x + x for x in sizes]
+    order = sorted(range(len(sizes)), key=lambda b: (-sizes[b], b))
+    heap = [(0, r) for r in range(world_size)]
     heapq.heapify(heap)
     owner = np.zeros(len(sizes), dtype=np.int64)
     for b in order:
         load, r = heapq.heappop(heap)
         owner[b] = r
-        heapq.heappush(heap, (load + cost[b], r))
+        heapq.heappush(heap, (min(load + cost[b], 2 ** 64 - 1), r))
+    return owner
+
+
+def partition_buckets(sizes, world_size):
+    """The library's bucket -> rank assignment (umi_partition_buckets: longest processing time
+    first on n_b^2 + n_b, deterministic: every rank computes the same answer from the same
+    sizes).  Returns a list of ascending bucket-index arrays, one per rank."""
+    from .api import partition_buckets as lib_partition
+    sizes = np.asarray(sizes, dtype=np.int64)
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    owner = lib_partition(off, world_size)
     return [np.nonzero(owner == r)[0] for r in range(world_size)]
 
 
@@ -61,39 +75,96 @@ def allgatherv_mask(local_bits, counts, dist, device=None):
 class ShardedDedup:
     """Runs the batched hot path on this rank's buckets and gathers the global mask.
 
-    compute(keys, nmask, freq, bucket_off) -> kept uint8[n_local] is the per-GPU hot
-    path (default: Context.dedup_batch through libumihip.so; tests on CPU/gloo pass
-    the oracle here -- the product default never does)."""
+    Default (compute=None): the HIP path.  This rank's shard is uploaded once and stays on the
+    GPU; a run is Context.dedup_batch_device on it, the kept mask packed to bits on the device
+    (umi_pack_mask_device) and all-gathered as padded slices (RCCL over xGMI under "nccl").
+    compute(keys, nmask, freq, bucket_off) -> kept uint8[n_local] replaces the per-GPU hot
+    path with host code: the CPU tests (gloo, no GPU) pass the oracle here -- the product
+    default never does."""
 
-    def __init__(self, dist, compute):
+    def __init__(self, dist, compute=None, ctx=None, umi_len=None, k=1, percentage=0.5, algo=0,
+                 adj_max_freq=0):
         self.dist = dist
         self.compute = compute
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
+        self.ctx = ctx
+        self.params = dict(umi_len=umi_len, k=k, percentage=percentage, algo=algo, adj_max_freq=adj_max_freq)
+        self._shard = None
 
-    def run(self, keys, nmask, freq, bucket_off):
-        import torch
+    def shard(self, keys, nmask, freq, bucket_off):
+        """Select this rank's buckets; on the HIP path, upload them (once) to the GPU."""
         bucket_off = np.asarray(bucket_off, dtype=np.uint64)
         sizes = np.diff(bucket_off.astype(np.int64))
         parts = partition_buckets(sizes, self.world)
-        mine = parts[self.rank]
-        lk, lnm, lf, loff, gidx = shard_arrays(keys, nmask, freq, bucket_off, mine)
-        kept_local = np.asarray(self.compute(lk, lnm, lf, loff), dtype=np.uint8)
-        # slice sizes of every rank are known from the partition: no size exchange
-        n_local = [int(sizes[p].sum()) for p in parts]
-        counts = [(n + 7) // 8 for n in n_local]
+        lk, lnm, lf, loff, _ = shard_arrays(keys, nmask, freq, bucket_off, parts[self.rank])
+        sh = dict(parts=parts, bucket_off=bucket_off, n_local=[int(sizes[p].sum()) for p in parts], loff=loff)
+        if self.compute is None:
+            import torch
+            if self.ctx is None:
+                from .api import Context
+                self.ctx = Context(torch.cuda.current_device())
+            dev = torch.device("cuda", torch.cuda.current_device())
+            sh["d_keys"] = torch.from_numpy(lk.view(np.int64)).to(dev)
+            sh["d_nmask"] = None if lnm is None else torch.from_numpy(lnm.view(np.int64)).to(dev)
+            sh["d_freq"] = torch.from_numpy(lf).to(dev)
+            sh["d_kept"] = torch.zeros(max(1, len(lk)), dtype=torch.uint8, device=dev)
+            mx = max(1, (max(sh["n_local"]) + 7) // 8)
+            sh["d_bits"] = torch.zeros(mx, dtype=torch.uint8, device=dev)
+            sh["d_all"] = torch.zeros(mx * self.world, dtype=torch.uint8, device=dev)
+        else:
+            sh["host"] = (lk, lnm, lf)
+        self._shard = sh
+        return sh
+
+    def run_resident(self):
+        """One pass over the resident shard.  Returns the packed masks of all ranks: a list of
+        uint8 tensors (bits, little-endian per byte), slice r holding rank r's entries in its own
+        shard order.  On the HIP path nothing leaves the GPU but the gathered bits."""
+        import torch
+        sh = self._shard
+        counts = [(n + 7) // 8 for n in sh["n_local"]]
+        if self.compute is None:
+            n = sh["n_local"][self.rank]
+            stream = torch.cuda.current_stream().cuda_stream
+            p = self.params
+            if n:
+                self.ctx.dedup_batch_device(sh["d_keys"].data_ptr(),
+                                            0 if sh["d_nmask"] is None else sh["d_nmask"].data_ptr(),
+                                            sh["d_freq"].data_ptr(), sh["loff"], p["umi_len"], sh["d_kept"].data_ptr(), 0,
+                                            k=p["k"], percentage=p["percentage"], algo=p["algo"],
+                                            adj_max_freq=p["adj_max_freq"], stream=stream)
+                self.ctx.pack_mask_device(sh["d_kept"].data_ptr(), n, sh["d_bits"].data_ptr(), stream=stream)
+            mx = sh["d_bits"].numel()
+            if self.dist.get_backend() == "nccl":  # RCCL over xGMI: device to device
+                self.dist.all_gather_into_tensor(sh["d_all"], sh["d_bits"])
+                out = sh["d_all"]
+            else:  # a rehearsal over gloo (several ranks on one GPU): the packed slice via the host
+                out = torch.empty(mx * self.world, dtype=torch.uint8)
+                self.dist.all_gather_into_tensor(out, sh["d_bits"].cpu())
+            return [out[r * mx: r * mx + counts[r]] for r in range(self.world)]
+        lk, lnm, lf = sh["host"]
+        kept_local = np.asarray(self.compute(lk, lnm, lf, sh["loff"]), dtype=np.uint8)
         backend = self.dist.get_backend()
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu"
         bits = torch.from_numpy(np.packbits(kept_local, bitorder="little")).to(dev)
-        gathered = allgatherv_mask(bits, counts, self.dist)
-        kept = np.zeros(int(bucket_off[-1]), dtype=np.uint8)
+        return allgatherv_mask(bits, counts, self.dist)
+
+    def run(self, keys, nmask, freq, bucket_off):
+        """shard + one pass + the global kept mask as a host array (uint8[N])."""
+        import torch
+        sh = self.shard(keys, nmask, freq, bucket_off)
+        gathered = self.run_resident()
+        kept = np.zeros(int(sh["bucket_off"][-1]), dtype=np.uint8)
         for r in range(self.world):
-            if n_local[r] == 0:
+            if sh["n_local"][r] == 0:
                 continue
-            kr = np.unpackbits(gathered[r].cpu().numpy(), bitorder="little")[: n_local[r]]
-            kept[_global_index(bucket_off, parts[r])] = kr
+            kr = np.unpackbits(gathered[r].cpu().numpy(), bitorder="little")[: sh["n_local"][r]]
+            kept[_global_index(sh["bucket_off"], sh["parts"][r])] = kr
         # additive counters of deduplicate_sam.rs:217-219
-        tot = torch.tensor([int(kept_local.sum())], dtype=torch.int64, device=dev)
+        mine = kept[_global_index(sh["bucket_off"], sh["parts"][self.rank])] if sh["n_local"][self.rank] else kept[:0]
+        dev = gathered[0].device
+        tot = torch.tensor([int(mine.sum())], dtype=torch.int64, device=dev)
         self.dist.all_reduce(tot)
         assert int(tot.item()) == int(kept.sum())
         return kept
@@ -149,8 +220,8 @@ def split_dedup_device(ctx, dist, d_keys, d_nmask, d_freq, bucket_off, umi_len, 
                 d_freq.data_ptr(), bucket_off, umi_len, rank, world, buf.data_ptr(), cap, k=k,
                 percentage=percentage, algo=algo, adj_max_freq=adj_max_freq, stream=stream)
             break
-        except Exception as e:  # UMI_ERR_NOMEM: the message carries the count; grow and redo
-            if getattr(e, "code", 0) != -4:
+        except UmiHipError as e:  # UMI_ERR_NOMEM: the list did not fit; grow and redo
+            if e.code != UMI_ERR_NOMEM:
                 raise
             cap *= 4
     edges = allgatherv_edges(buf[:ne], dist)
