@@ -195,3 +195,102 @@ def test_config5_shape_20bp_k2(ctx):
     kept2, root2, _ = ctx.dedup_batch(k2, None, f2, o2, 20, k=2)
     ok, oroot, _ = orc.dedup_batch(k2, None, f2, o2, 20, 2)
     assert (kept2 == ok).all() and (root2 == oroot).all()
+
+
+def _oracle_on_every_nth_bucket(keys, freq, off, kept, root, umi_len, k, step):
+    for b in range(0, len(off) - 1, step):
+        s, e = int(off[b]), int(off[b + 1])
+        ok, oroot, _ = orc.dedup_batch(keys[s:e], None, freq[s:e], [0, e - s], umi_len, k)
+        assert (kept[s:e] == ok).all() and (root[s:e] - s == oroot).all(), b
+
+
+@pytest.mark.parametrize("name,n_reads,umi_len,k,seed", [
+    ("config 4: one GPU's share of 100M reads in 10^6 positions", 12_500_000, 12, 1, 4),
+    ("config 5: one GPU's share of 50M reads, 20-bp, k = 2", 6_250_000, 20, 2, 5)])
+def test_per_gpu_share_of_the_8_gpu_configs(ctx, name, n_reads, umi_len, k, seed):
+    """BASELINE configs 4 and 5 are 8-GPU jobs; what one GPU gets of them (bucket sharding: an
+    eighth of the positions) at full size: structure (P1), the oracle on every ~100th bucket (P5),
+    and the same call through a two-device context (both workers on this GPU) bit for bit."""
+    import umi_collapse_rs_amd as umi
+    from umi_collapse_rs_amd import synth
+    st = synth.config3(seed=seed, n_reads=n_reads, n_positions=n_reads // 100, umi_len=umi_len)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    assert len(off) - 1 == n_reads // 100
+    kept, root, stats = ctx.dedup_batch(keys, None, freq, off, umi_len, k=k, percentage=0.5)
+    assert stats["n_kept"] == int(kept.sum()) and stats["n_buckets"] == n_reads // 100
+    check_structure(kept, root, off)
+    _oracle_on_every_nth_bucket(keys, freq, off, kept, root, umi_len, k, 101)
+    multi = umi.Context([0, 0])
+    try:
+        mkept, mroot, mst = multi.dedup_batch(keys, None, freq, off, umi_len, k=k, percentage=0.5)
+    finally:
+        multi.close()
+    assert (mkept == kept).all() and (mroot == root).all()
+    assert mst["n_kept"] == stats["n_kept"] and mst["n_pairs"] == stats["n_pairs"]
+
+
+def test_config2m_molecule_model_deep_position(ctx):
+    """One deep position from the molecule model (clusters: a true UMI of high freq with its freq-1
+    error copies around it): fixed point (P2) on a sample, cross-kernel equality with the key-sorted
+    scan + walk and the unsorted all-pairs mask kernel, oracle on a 40k-entry cut of the same data."""
+    import umi_collapse_rs_amd as umi
+    from umi_collapse_rs_amd import synth
+    st = synth.config2m(seed=22, n_reads=1_000_000, umi_len=12)
+    keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+    assert 150_000 < len(keys) < 400_000 and freq[0] > 50
+    kept, root, stats = ctx.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+    check_structure(kept, root, off)
+    rng = np.random.default_rng(5)
+    sample = np.concatenate([rng.choice(len(keys), 150, replace=False), np.nonzero(kept == 0)[0][:50],
+                             np.arange(20)])
+    check_fixed_point(keys, freq, root, off, 1, 0.5, sample, rng)
+    for opts in ({"seg_index": 0}, {"seg_index": 0, "bs_sorted": 0}):
+        c = umi.Context(0)
+        try:
+            for name, v in opts.items():
+                c.set_option(name, v)
+            k2, r2, st2 = c.dedup_batch(keys, None, freq, off, 12, k=1, percentage=0.5)
+        finally:
+            c.close()
+        assert (k2 == kept).all() and (r2 == root).all() and st2["n_edges"] == stats["n_edges"]
+    # the first 40,000 entries in rank order (the high-freq true UMIs and a share of the rest)
+    m = 40_000
+    ok, oroot, _ = orc.dedup_batch(keys[:m], None, freq[:m], [0, m], 12, 1)
+    kk, rr, _ = ctx.dedup_batch(keys[:m], None, freq[:m], [0, m], 12, k=1)
+    assert (kk == ok).all() and (rr == oroot).all()
+
+
+def test_large_and_small_calls_alternate_on_one_context():
+    """Regression for the staging buffers of the plan (round 1 saw a host segfault in a
+    development build when a small single-bucket call followed a large all-fused one on the same
+    context: the first call that reached the pinned task staging after calls that never had).
+    Calls of very different shapes alternate on ONE context, each checked against the oracle:
+    every grow-only device and pinned buffer is reused at a smaller size, regrown, reused."""
+    import umi_collapse_rs_amd as umi
+    from umi_collapse_rs_amd import synth
+    rng = np.random.default_rng(77)
+    big20 = synth.config3(seed=5, n_reads=1_270_000, n_positions=20_000, umi_len=20)  # all buckets fused
+    raw = rng.integers(0, 4, (11_000, 20), dtype=np.uint8)
+    raw[:, 8:] = raw[:1, 8:]  # 8 free bases: one dense 20-bp bucket of ~9,000 entries
+    one20 = synth.stage(np.zeros(len(raw), np.int64), synth.bases_to_keys(raw))
+    deep12 = synth.config2(seed=9, n_reads=60_000, umi_len=9)
+    many12 = synth.config3(seed=3, n_reads=300_000, n_positions=3_000, umi_len=12)
+    assert 7_000 < len(one20["keys"]) < 11_000
+    calls = [(big20, 20, 2, None), (one20, 20, 2, "full"), (deep12, 9, 1, "full"), (big20, 20, 2, None),
+             (many12, 12, 1, "sample"), (one20, 20, 2, "full"), (deep12, 9, 1, "full"), (many12, 12, 1, "sample")]
+    for opts in ({}, {"seg_index": 0}):
+        c = umi.Context(0)
+        try:
+            for name, v in opts.items():
+                c.set_option(name, v)
+            for st, L, k, check in calls:
+                keys, freq, off = st["keys"], st["freq"], st["bucket_off"]
+                kept, root, stats = c.dedup_batch(keys, None, freq, off, L, k=k)
+                check_structure(kept, root, off)
+                if check == "full":
+                    ok, oroot, _ = orc.dedup_batch(keys, None, freq, off, L, k)
+                    assert (kept == ok).all() and (root == oroot).all()
+                elif check == "sample":
+                    _oracle_on_every_nth_bucket(keys, freq, off, kept, root, L, k, 37)
+        finally:
+            c.close()
