@@ -38,8 +38,8 @@ def phase_of(name):
 
 
 def short(name):
-    n = name.split("(")[0]
-    n = n.replace("umihip::(anonymous namespace)::", "").replace("void ", "")
+    n = name.replace("umihip::(anonymous namespace)::", "").replace("void ", "")
+    n = n.split("(")[0]
     return n.strip()[:80]
 
 
