@@ -474,3 +474,34 @@ def test_device_pointer_entry_point(ctx):
     assert (t_kept.cpu().numpy() == okept).all()
     assert (t_root.cpu().numpy().view(np.uint32) == oroot).all()
     assert st["n_kept"] == int(okept.sum())
+
+
+@pytest.mark.parametrize("L,k,n_raw,n_frac", [
+    (10, 1, 42000, 0.0),    # one segment of ~40k entries: three 16k-entry blocks of the LDS counting sort
+    (9, 2, 40000, 0.002),   # three parts, N bases
+    (18, 2, 34000, 0.001),  # 64-bit keys
+])
+def test_segment_index_counting_sort_and_union_variants(L, k, n_raw, n_frac):
+    """The segment index with its counting sort through per-block LDS histograms or per-entry
+    atomics (seg_lds), symmetric pairs united where they are found or through the edge list
+    (seg_unite): every combination against the oracle, same edge count; a deep position next to
+    mid-size ones (several segments in one call, one of them spanning several blocks)."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(77 * L + k)
+    keys, nm, fr, off = _wide_bucket(rng, n_raw, L, n_frac)
+    k2, n2, f2, o2 = make_batch(rng, 6, L, 900, err=0.05, n_frac=n_frac, exact=True)  # segments of ~600-2000 entries
+    keys = np.concatenate([k2, keys]); nm = np.concatenate([n2, nm]); fr = np.concatenate([f2, fr])
+    off = np.concatenate([o2, o2[-1] + off[1:]]).astype(np.uint64)
+    c = umi.Context(0)
+    try:
+        ref = None
+        for lds in (1, 0):
+            for unite in (1, 0):
+                c.set_option("seg_lds", lds)
+                c.set_option("seg_unite", unite)
+                st = check_against_oracle(c, keys, nm, fr, off, L, k)
+                assert st["n_edges"] > 0
+                ref = ref or st
+                assert st["n_edges"] == ref["n_edges"] and st["n_pairs_evaluated"] == ref["n_pairs_evaluated"]
+    finally:
+        c.close()

@@ -144,6 +144,9 @@ struct umi_ctx {
     uint32_t seg_min = 512;  // ... from this many entries up
     uint64_t split_min = 200000; // multi-device: a bucket at least this large that dominates the call
                                  // has its pairs split over the devices instead of the buckets
+    bool seg_unite = true;   // its pair kernel unites symmetric pairs on the spot (batched directional path)
+    bool seg_lds = true;     // counting sort of the partition through per-block LDS histograms (where
+                             // every part has at most SEG_LDS_BINS bins), else one atomic per entry
     uint32_t seg_dbg = 0;
     uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: 24 per CU, all resident at once)
     // workspace
@@ -308,7 +311,8 @@ class Pipeline {
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
-    uint64_t n_edges = 0;
+    uint64_t n_edges = 0;  // entries the pair kernels appended to the edge list
+    uint64_t n_direct = 0; // symmetric pairs united where they were found
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
     const uint32_t *bs_perm = nullptr;
@@ -317,6 +321,7 @@ class Pipeline {
     const SegDesc *d_segs = nullptr;
     const SegScanChunk *d_chunks = nullptr;
     const PairTask *d_small = nullptr, *d_big = nullptr;
+    const SegBlock *d_seg_blocks = nullptr;
     SegArgs seg;
 
     // The bit-sliced tile kernels of the earlier versions (options bs_sorted / bs_tables / prune,
@@ -441,6 +446,7 @@ class Pipeline {
         const size_t o_ranges = place(pl.ranges.size() * sizeof(RangeTask));
         const size_t o_segs = place(pl.segs.size() * sizeof(SegDesc));
         const size_t o_chunks = place(pl.seg_chunks.size() * sizeof(SegScanChunk));
+        const size_t o_blocks = place(pl.seg_blocks.size() * sizeof(SegBlock));
         const size_t o_small = place(pl.small_tasks.size() * sizeof(PairTask));
         const size_t o_big = place(pl.big_tasks.size() * sizeof(PairTask));
         const size_t total = std::max<size_t>(off, 64);
@@ -448,6 +454,7 @@ class Pipeline {
         if ((rc = ctx->h_plan.put(o_ranges, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask))) ||
             (rc = ctx->h_plan.put(o_segs, pl.segs.data(), pl.segs.size() * sizeof(SegDesc))) ||
             (rc = ctx->h_plan.put(o_chunks, pl.seg_chunks.data(), pl.seg_chunks.size() * sizeof(SegScanChunk))) ||
+            (rc = ctx->h_plan.put(o_blocks, pl.seg_blocks.data(), pl.seg_blocks.size() * sizeof(SegBlock))) ||
             (rc = ctx->h_plan.put(o_small, pl.small_tasks.data(), pl.small_tasks.size() * sizeof(PairTask))) ||
             (rc = ctx->h_plan.put(o_big, pl.big_tasks.data(), pl.big_tasks.size() * sizeof(PairTask))))
             return rc;
@@ -456,6 +463,7 @@ class Pipeline {
         d_ranges = (const RangeTask *)(d + o_ranges);
         d_segs = (const SegDesc *)(d + o_segs);
         d_chunks = (const SegScanChunk *)(d + o_chunks);
+        d_seg_blocks = (const SegBlock *)(d + o_blocks);
         d_small = (const PairTask *)(d + o_small);
         d_big = (const PairTask *)(d + o_big);
 
@@ -487,6 +495,11 @@ class Pipeline {
             seg.ranges = d_ranges;
             seg.n_ranges = (uint32_t)pl.ranges.size();
             seg.dbg = ctx->seg_dbg;
+            if (ctx->seg_lds && pl.seg_max_bins <= SEG_LDS_BINS && !pl.seg_blocks.empty()) {
+                seg.blocks = d_seg_blocks;
+                seg.n_blocks = (uint32_t)pl.seg_blocks.size();
+                seg.lds_bins = pl.seg_max_bins;
+            }
             HIP_TRY(hipMemsetAsync(seg.bin_cnt, 0, pl.seg_bins * 4, s));
         }
         return UMI_OK;
@@ -546,7 +559,7 @@ class Pipeline {
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, d_ranges,
                             (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
                             ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), d_cnt,
-                            seg.n_chunks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
+                            seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
         return UMI_OK;
     }
 
@@ -719,6 +732,7 @@ class Pipeline {
             seg.priv_edges = ctx->seg_priv_edges.as<uint2>();
             seg.priv_dist = ctx->seg_priv_dist.as<uint8_t>();
             seg.priv_cnt = ctx->seg_priv_cnt.as<uint32_t>();
+            seg.uf_parent = one_sync() && ctx->seg_unite ? ctx->label.as<uint32_t>() : nullptr;
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             st.n_pair_launches += 1;
         }
@@ -753,6 +767,7 @@ class Pipeline {
     void note_pair_counters()
     {
         n_edges = ctx->h_counters[CNT_EDGES];
+        n_direct = ctx->h_counters[CNT_UF_DIRECT];
         st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
         st.n_pairs_evaluated = pl.n_pairs_eval + ctx->h_counters[CNT_SEG_PAIRS];
         if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
@@ -862,11 +877,12 @@ class Pipeline {
             ctx->edge_capacity = cap;
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UF_DIRECT], 0, sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1), s));
             HIP_TRY(launch_iota(d_label, n, s)); // (the fused buckets' entries are finished: their labels are free)
         }
-        st.n_edges = n_edges;
-        int rounds = have_pairs && n_edges ? 1 : 0;
+        st.n_edges = n_edges + n_direct;
+        int rounds = have_pairs && st.n_edges ? 1 : 0;
         for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
         if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
             const uint2 *d_edges = ctx->edges.as<uint2>();
@@ -1444,6 +1460,10 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->two_phase = (int)value;
     } else if (!strcmp(name, "seg_index")) {
         ctx->seg_index = value != 0;
+    } else if (!strcmp(name, "seg_unite")) {
+        ctx->seg_unite = value != 0;
+    } else if (!strcmp(name, "seg_lds")) {
+        ctx->seg_lds = value != 0;
     } else if (!strcmp(name, "seg_dbg")) {
         ctx->seg_dbg = (uint32_t)value;
     } else if (!strcmp(name, "seg_blocks")) {

@@ -40,6 +40,7 @@ enum Counter : int {
     CNT_SEG_TASKS = 12, // segment index: (sub-bucket, 64-row chunk) tasks its scan produced
     CNT_SEG_PAIRS = 13, // ... and the pairs inside its sub-buckets (what the pair kernel compares)
     CNT_KEPT_FUSED = 14, // survivors of the buckets the fused one-wave kernel finished by itself
+    CNT_UF_DIRECT = 15, // symmetric pairs the segment index's pair kernel united on the spot (not in the list)
     CNT_COUNT = 16,
 };
 // The flags of the collapse rounds ("round r changed a label") sit behind the counters in the
@@ -108,6 +109,19 @@ struct SegTask {
     uint32_t row0, end;
     uint32_t seg, part;
 };
+// One block of the counting sort's LDS path: entries [start, end) of segment `seg`
+// (<= SEG_BLOCK_ENTRIES of them).  The block counts its entries per bin in LDS and touches a bin's
+// global word once (count pass: one add; scatter pass: one returning add that reserves the
+// block's run inside the bin), so a bin's word takes one atomic per block instead of one per entry
+// -- device-scope atomics are served at the memory side of the fabric (~3e10 per second over the
+// whole chip, ~90 per microsecond on one word), which is what bounded the per-entry version.
+struct SegBlock {
+    uint32_t start, end;
+    uint32_t seg, pad;
+};
+constexpr uint32_t SEG_BLOCK_THREADS = 1024;
+constexpr uint32_t SEG_BLOCK_ENTRIES = 16 * SEG_BLOCK_THREADS;
+constexpr uint32_t SEG_LDS_BINS = 16384; // bins of one part the LDS path takes (64 KB of counters)
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
 constexpr int BS_TAB_G = 1;     // row groups of 32 per lane of the table variant (a wave: 64 * 32 * G rows)
@@ -178,12 +192,18 @@ struct SegArgs {
                             // 16-byte store per entry and part
     const RangeTask *ranges;
     uint32_t n_ranges;
+    const SegBlock *blocks; // LDS path of the counting sort (null: per-entry atomics, histogram by prep)
+    uint32_t n_blocks;
+    uint32_t lds_bins;      // most bins any part of any segment has
     // the pair kernel's blocks leave what their edge stage still holds at the end in a slot of their
     // own; seg_edge_append moves the slots to the edge list (no storm of atomics on the list's
     // counter when all blocks finish together)
     uint2 *priv_edges;      // [n_blocks * SEG_PRIV_CAP]
     uint8_t *priv_dist;     // ... their distances (DataStruct mode), else null
     uint32_t *priv_cnt;     // [n_blocks] entries in each slot, then (after the scan) their offsets
+    // directional batched path: parent array of the union-find (= label[]).  A pair permitted in both
+    // directions is united where it is found instead of going through the edge list (null: listed)
+    uint32_t *uf_parent;
     uint32_t dbg; // tuning experiments only (ctx option seg_dbg): 1 drop the queued hits, 2 skip the column loop
 };
 // exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];

@@ -180,6 +180,99 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(SegArgs g, const KeyT 
     }
 }
 
+// ---- the counting sort's LDS path --------------------------------------------------------------
+// A block of 1024 threads owns up to SEG_BLOCK_ENTRIES consecutive entries of one segment (their
+// filter keys stay in L2 between the passes) and takes the segment's parts one after the other:
+// the block's entries are counted per bin in LDS, and a bin's global word is touched once per
+// block.  Count pass: one add of the block's count.  Scatter pass (after the scan has turned the
+// totals into bin_start and cleared the words): one returning add that reserves the block's run
+// inside the bin; the position of an entry is then bin_start + run start + an LDS counter.
+// A (block, bin) run is contiguous in the sub-bucket arrays, so the 16-byte records of a block
+// fill whole lines instead of landing one by one.
+// count the block's entries per bin of part (b0, nb) into hist[] (LDS, cleared first)
+template <typename KeyT>
+__device__ __forceinline__ void seg_block_histogram(const SegBlock &blk, const KeyT *__restrict__ fkey, int b0,
+                                                    int nb, uint32_t nbins, uint32_t *hist)
+{
+    for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) hist[b] = 0;
+    __syncthreads();
+    constexpr int B = 8; // loads in flight per thread
+    for (uint32_t i0 = blk.start + threadIdx.x; i0 < blk.end; i0 += B * SEG_BLOCK_THREADS) {
+        KeyT key[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
+            key[q] = i < blk.end ? fkey[i] : KeyT(0);
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++)
+            if (i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end) atomicAdd(&hist[seg_part_bits(key[q], b0, nb)], 1u);
+    }
+    __syncthreads();
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_count_lds_kernel(SegArgs g, const KeyT *__restrict__ fkey)
+{
+    extern __shared__ uint32_t hist[];
+    const SegBlock blk = g.blocks[blockIdx.x];
+    const SegDesc *__restrict__ sd = g.segs + blk.seg;
+    for (int j = 0; j < g.n_parts; j++) {
+        const int b0 = sd->b0[j], nb = sd->nb[j];
+        const uint32_t nbins = 1u << (2 * nb), bin_off = sd->bin_off[j];
+        seg_block_histogram(blk, fkey, b0, nb, nbins, hist);
+        for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) {
+            const uint32_t c = hist[b];
+            if (c) atomicAdd(&g.bin_cnt[bin_off + b], c);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_scatter_lds_kernel(SegArgs g, const KeyT *__restrict__ fkey,
+                                                                            const int32_t *__restrict__ freq)
+{
+    using Rec = typename SegRecOf<KeyT>::type;
+    extern __shared__ uint32_t hist[];
+    const SegBlock blk = g.blocks[blockIdx.x];
+    const SegDesc *__restrict__ sd = g.segs + blk.seg;
+    Rec *__restrict__ sub = (Rec *)g.sub_rec;
+    for (int j = 0; j < g.n_parts; j++) {
+        const int b0 = sd->b0[j], nb = sd->nb[j];
+        const uint32_t nbins = 1u << (2 * nb), bin_off = sd->bin_off[j];
+        seg_block_histogram(blk, fkey, b0, nb, nbins, hist);
+        // the block's run inside every bin it has entries for: hist[b] becomes its first position
+        for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) {
+            const uint32_t c = hist[b];
+            if (c) hist[b] = g.bin_start[bin_off + b] + atomicAdd(&g.bin_cnt[bin_off + b], c);
+        }
+        __syncthreads();
+        constexpr int B = 8;
+        for (uint32_t i0 = blk.start + threadIdx.x; i0 < blk.end; i0 += B * SEG_BLOCK_THREADS) {
+            KeyT key[B];
+            int32_t f[B];
+            uint32_t pos[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
+                key[q] = i < blk.end ? fkey[i] : KeyT(0);
+                f[q] = i < blk.end ? freq[i] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < B; q++)
+                pos[q] = i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end
+                             ? atomicAdd(&hist[seg_part_bits(key[q], b0, nb)], 1u) : 0u;
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
+                if (i < blk.end) sub[pos[q]] = make_rec(key[q], i, f[q]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ uint32_t readlane_key(uint32_t v, int lane)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -233,7 +326,7 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
     }
     __syncthreads();
     const uint32_t n_tasks = (uint32_t)min((unsigned long long)g.task_cap, a.counters[CNT_SEG_TASKS]);
-    unsigned int n_cand = 0;
+    unsigned int n_cand = 0, n_direct = 0;
     // masks of the bins of the parts before the task's own: a pair that shares one of them was
     // reported there.  Kept while the tasks stay in one (segment, part): nearly always.
     KeyT dup_mask[SEG_MAX_PARTS - 1];
@@ -282,8 +375,14 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                                 fwd = fj <= a.adj_max_freq;
                                 bwd = false;
                             }
-                            if (fwd && bwd)
-                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi | SYM_FLAG, gj, dist, false);
+                            if (fwd && bwd) {
+                                if (g.uf_parent) { // reachability inside such a set is symmetric: one set
+                                    uf_union(g.uf_parent, gi, gj);
+                                    n_direct++;
+                                } else {
+                                    emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi | SYM_FLAG, gj, dist, false);
+                                }
+                            }
                             else if (fwd)
                                 emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, false);
                             else if (bwd)
@@ -380,6 +479,8 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
     }
     for (int off = 32; off > 0; off >>= 1) n_cand += __shfl_down(n_cand, off);
     if (lane == 0 && n_cand) atomicAdd(&a.counters[CNT_CANDIDATES], (unsigned long long)n_cand);
+    for (int off = 32; off > 0; off >>= 1) n_direct += __shfl_down(n_direct, off);
+    if (lane == 0 && n_direct) atomicAdd(&a.counters[CNT_UF_DIRECT], (unsigned long long)n_direct);
 }
 
 // offsets of the blocks' slots behind what the list holds already (one block), the new total
@@ -435,11 +536,21 @@ hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *f
                             unsigned long long *counters, hipStream_t s)
 {
     if (g.n_chunks == 0 || g.n_ranges == 0) return hipSuccess;
+    const size_t lds = (size_t)g.lds_bins * sizeof(uint32_t);
+    if (g.blocks) { // the histogram (else prep_kernel has counted the entries, one atomic each)
+        if (key32) seg_count_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint32_t *)fkey);
+        else seg_count_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint64_t *)fkey);
+    }
     seg_scan_reduce_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g);
     seg_scan_spine_kernel<<<1, 1024, 0, s>>>(g, counters);
     seg_scan_apply_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g, counters);
-    if (key32) seg_scatter_kernel<uint32_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint32_t *)fkey, freq);
-    else seg_scatter_kernel<uint64_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint64_t *)fkey, freq);
+    if (g.blocks) {
+        if (key32) seg_scatter_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint32_t *)fkey, freq);
+        else seg_scatter_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint64_t *)fkey, freq);
+    } else {
+        if (key32) seg_scatter_kernel<uint32_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint32_t *)fkey, freq);
+        else seg_scatter_kernel<uint64_t><<<g.n_ranges, 256, 0, s>>>(g, (const uint64_t *)fkey, freq);
+    }
     return hipGetLastError();
 }
 
