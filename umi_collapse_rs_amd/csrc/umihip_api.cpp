@@ -499,6 +499,7 @@ class Pipeline {
                 seg.blocks = d_seg_blocks;
                 seg.n_blocks = (uint32_t)pl.seg_blocks.size();
                 seg.lds_bins = pl.seg_max_bins;
+                seg.parts_per_pass = std::max(1u, std::min({4u, (uint32_t)pl.seg_parts, SEG_LDS_BINS / std::max(1u, pl.seg_max_bins)}));
             }
             HIP_TRY(hipMemsetAsync(seg.bin_cnt, 0, pl.seg_bins * 4, s));
         }
@@ -558,7 +559,7 @@ class Pipeline {
     {
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, d_ranges,
                             (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
-                            ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), d_cnt,
+                            ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), nullptr, d_cnt,
                             seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
         return UMI_OK;
     }
@@ -857,14 +858,18 @@ class Pipeline {
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             const uint2 *d_edges = ctx->edges.as<uint2>();
             if (have_pairs) {
-                HIP_TRY(launch_uf_components(d_edges, d_cnt, cap_used, d_label, d_lab, n, cap_used, s));
+                // symmetric pairs in the list: those of the tile kernels, and the segment index's
+                // when it does not unite them itself
+                if (!seg.uf_parent || legacy_tiles() || !pl.small_tasks.empty() || !pl.big_tasks.empty())
+                    HIP_TRY(launch_uf_union_list(d_edges, d_cnt, cap_used, d_label, cap_used, s));
+                HIP_TRY(launch_uf_flatten(d_label, d_lab, n, s));
                 for (int r = 0; r < DAG_ROUNDS; r++)
-                    HIP_TRY(launch_dag_round(d_edges, d_cnt, cap_used, d_label, d_lab, n, d_changed, r, cap_used, s));
+                    HIP_TRY(launch_dag_flat_round(d_edges, d_cnt, cap_used, d_label, d_lab, d_changed, r, s));
             }
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
             if (have_pairs)
                 HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root,
-                                            d_cnt, s));
+                                            d_cnt, false, s));
             else // no pair of this call reaches the edge list: every entry outside the fused buckets survives
                 HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
@@ -886,12 +891,15 @@ class Pipeline {
         for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
         if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
             const uint2 *d_edges = ctx->edges.as<uint2>();
+            // (comp[] is flat and lab[] is monotone: the rounds go on where the first ones stopped, now
+            // with pointer jumps -- lab[] is the identity on the entries no one-way pair has touched)
             if ((rc = run_rounds(ctx, s, [&](uint32_t *dc, int r) {
                      return launch_dag_round(d_edges, d_cnt, cap_used, d_label, d_lab, n, dc, r, cap_used, s);
                  }, rounds, 4)))
                 return rc;
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
-            HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
+            HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt,
+                                        false, s));
             if ((rc = read_control())) return rc;
         }
         st.n_rounds = (uint32_t)rounds;

@@ -29,7 +29,62 @@ __global__ __launch_bounds__(256) void uf_union_kernel(const uint2 *__restrict__
     }
 }
 
-// comp[v] = root of v (the smallest index of its set); lab[v] = v
+// root of v in the forest (read-only: the unions are over)
+__device__ __forceinline__ uint32_t uf_root(const uint32_t *__restrict__ parent, uint32_t v)
+{
+    uint32_t r = parent[v];
+    if (r != v)
+        for (;;) {
+            const uint32_t p = parent[r];
+            if (p == r) break;
+            r = p;
+        }
+    return r;
+}
+
+// One round along the one-way pairs over the flattened sets: lab[set of v] = min(.., lab[set of u])
+// for every listed pair u -> v (directional.rs:38-39: v falls to whatever removes u).  No pointer
+// jump over lab[] behind it: a chain of one-way pairs is as deep as the freq ladder it descends,
+// two or three steps, and a pass over all of lab[] per round costs more than the round it might
+// save.  (Climbing the forest as the unions left it instead of flattening it first was measured
+// and dropped: its trees are deep enough that the climbs of this kernel and of the final pass cost
+// more than the flatten pass, 36 + 44 us against 24 + 5 + 11.)  Only as many blocks work as the list needs (the grid is sized for the list's
+// capacity, the count is on the device): the fewer waves, the more of a hot word's hooks meet in
+// one wave's registers.
+__global__ __launch_bounds__(256) void dag_flat_hook_kernel(const uint2 *__restrict__ edges,
+                                                            const unsigned long long *counters,
+                                                            uint32_t edge_cap,
+                                                            const uint32_t *__restrict__ comp,
+                                                            uint32_t *lab, uint32_t *changed, int round)
+{
+    if (round > 0 && changed[round - 1] == 0) return;
+    const unsigned long long ne = counters[CNT_EDGES];
+    const uint32_t E = ne < edge_cap ? (uint32_t)ne : edge_cap;
+    constexpr uint32_t PER_BLOCK = 256 * 8;
+    const uint32_t active = min(gridDim.x, (E + PER_BLOCK - 1) / PER_BLOCK);
+    if (blockIdx.x >= active) return;
+    bool any = false;
+    HotMin hot;
+    // (every lane of a wave makes the same number of trips: the shuffles below need them all)
+    for (uint32_t e0 = blockIdx.x * blockDim.x; e0 < E; e0 += active * blockDim.x) {
+        const uint32_t e = e0 + threadIdx.x;
+        const uint2 uv = e < E ? edges[e] : make_uint2(SYM_FLAG, 0u);
+        bool todo = false;
+        uint32_t cv = 0, lu = 0;
+        if (!(uv.x & SYM_FLAG)) {
+            const uint32_t cu = comp[uv.x];
+            cv = comp[uv.y];
+            lu = lab[cu];
+            todo = lu < lab[cv];
+        }
+        any |= todo;
+        wave_atomic_min(lab, cv, lu, todo, hot);
+    }
+    hot_flush(lab, hot);
+    if (any) changed[round] = 1;
+}
+
+// comp[v] = root of v (the smallest index of its set); lab[v] = v (lab may be null)
 __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint32_t *lab, uint32_t n)
 {
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
@@ -42,13 +97,14 @@ __global__ __launch_bounds__(256) void uf_flatten_kernel(uint32_t *parent, uint3
             }
             st_parent(&parent[v], r);
         }
-        lab[v] = v;
+        if (lab) lab[v] = v;
     }
 }
 
 // kept / root / survivor count of the entries of ranges (null: all n) from comp and lab:
 // label[v] = lab[comp[v]] (directional.rs:30-54,78-88), kept <=> label == v
 // (deduplicate_sam.rs:217-231)
+template <bool FIND>
 __global__ __launch_bounds__(256) void map_finalize_kernel(const uint32_t *__restrict__ comp,
                                                            const uint32_t *__restrict__ lab,
                                                            const RangeTask *__restrict__ ranges, uint32_t n,
@@ -58,7 +114,7 @@ __global__ __launch_bounds__(256) void map_finalize_kernel(const uint32_t *__res
 {
     unsigned int cnt = 0;
     auto f = [&](uint32_t i) {
-        const uint32_t l = lab[comp[i]];
+        const uint32_t l = lab[FIND ? uf_root(comp, i) : comp[i]];
         const bool kp = l == i;
         kept[i] = kp ? 1 : 0;
         if (root) root[i] = l;
@@ -115,11 +171,35 @@ hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipS
 
 hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
                                uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
-                               unsigned long long *counters, hipStream_t s)
+                               unsigned long long *counters, bool find, hipStream_t s)
 {
     if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
-    map_finalize_kernel<<<ranges ? n_ranges : grid_of(n, 1024, 1024), 256, 0, s>>>(comp, lab, ranges, n, kept,
-                                                                                    root, counters);
+    const uint32_t grid = ranges ? n_ranges : grid_of(n, 1024, 1024);
+    if (find) map_finalize_kernel<true><<<grid, 256, 0, s>>>(comp, lab, ranges, n, kept, root, counters);
+    else map_finalize_kernel<false><<<grid, 256, 0, s>>>(comp, lab, ranges, n, kept, root, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_uf_union_list(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                uint32_t *parent, uint32_t n_edges_hint, hipStream_t s)
+{
+    uf_union_kernel<<<grid_of(n_edges_hint, 256, 4096), 256, 0, s>>>(edges, counters, edge_cap, parent);
+    return hipGetLastError();
+}
+
+hipError_t launch_dag_flat_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                 const uint32_t *comp, uint32_t *lab, uint32_t *changed, int round,
+                                 hipStream_t s)
+{
+    dag_flat_hook_kernel<<<grid_of(edge_cap, 256 * 8, 512), 256, 0, s>>>(edges, counters, edge_cap, comp, lab,
+                                                                        changed, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_uf_flatten(uint32_t *parent, uint32_t *lab, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    uf_flatten_kernel<<<grid_of(n, 256, 4096), 256, 0, s>>>(parent, lab, n);
     return hipGetLastError();
 }
 

@@ -260,3 +260,51 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t u, uint32_t 
 
 } // namespace
 } // namespace umihip
+
+// ---- min-label hooks onto hot words (cc_hook / dag_hook rounds) ---------------------------------
+namespace umihip {
+namespace {
+
+// atomicMin(&arr[idx], val) for the lanes with `todo`, all lanes of the wave calling together.
+// A single word takes ~90 atomics per microsecond, and hooks pile up on the roots of the big
+// trees: the lanes that share the first pending lane's target send one atomic for their
+// minimum, twice; what is left goes one by one.
+// A wave keeps the minimum for its hottest target (the leader target of its last trip: the root of
+// the giant component for most of them) in registers across the trips of its loop and sends it
+// once, when the target changes or the kernel ends.
+struct HotMin {
+    uint32_t t = 0xFFFFFFFFu, m = 0xFFFFFFFFu; // (wave-uniform)
+};
+__device__ __forceinline__ void hot_flush(uint32_t *arr, HotMin &h)
+{
+    // (a fresh look first: while this wave gathered, others have usually lowered the word)
+    if (h.t != 0xFFFFFFFFu && (threadIdx.x & 63) == 0 && __atomic_load_n(&arr[h.t], __ATOMIC_RELAXED) > h.m)
+        atomicMin(&arr[h.t], h.m);
+    h.t = 0xFFFFFFFFu;
+    h.m = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uint32_t val, bool todo, HotMin &h)
+{
+    for (int pass = 0; pass < 2 && __any(todo); pass++) {
+        const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
+        const uint32_t tgt = (uint32_t)__shfl((int)idx, leader);
+        const bool mine = todo && idx == tgt;
+        uint32_t m = mine ? val : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+        if (tgt == h.t) {
+            h.m = min(h.m, m);
+        } else if (pass == 0) { // the new hot target
+            hot_flush(arr, h);
+            h.t = tgt;
+            h.m = m;
+        } else if ((int)(threadIdx.x & 63) == leader && __atomic_load_n(&arr[tgt], __ATOMIC_RELAXED) > m) {
+            atomicMin(&arr[tgt], m);
+        }
+        todo = todo && !mine;
+    }
+    if (todo) atomicMin(&arr[idx], val);
+}
+
+} // namespace
+} // namespace umihip

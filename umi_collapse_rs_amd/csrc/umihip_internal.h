@@ -102,7 +102,7 @@ struct SegScanChunk {
     uint32_t bin0, nbins; // nbins <= SEG_SCAN_CHUNK
     uint32_t seg, part;
 };
-constexpr uint32_t SEG_SCAN_CHUNK = 4096;
+constexpr uint32_t SEG_SCAN_CHUNK = 1024;
 // One unit of sub-bucket work: rows [row0, min(row0 + 64, end)) against the later entries of the
 // sub-bucket, columns (row, end), all positions in the sub-bucket arrays.
 struct SegTask {
@@ -173,7 +173,7 @@ constexpr int COL_TILE = 1024; // column keys staged in LDS per step
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
-                       bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
                        uint32_t *bin_cnt, hipStream_t s);
 
@@ -195,6 +195,7 @@ struct SegArgs {
     const SegBlock *blocks; // LDS path of the counting sort (null: per-entry atomics, histogram by prep)
     uint32_t n_blocks;
     uint32_t lds_bins;      // most bins any part of any segment has
+    uint32_t parts_per_pass; // parts whose counters fit the LDS side by side (1..4)
     // the pair kernel's blocks leave what their edge stage still holds at the end in a slot of their
     // own; seg_edge_append moves the slots to the edge list (no storm of atomics on the list's
     // counter when all blocks finish together)
@@ -222,13 +223,24 @@ hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, flo
 hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
                                 uint32_t *comp, uint32_t *lab, uint32_t n, uint32_t n_edges_hint,
                                 hipStream_t s);
+// The batched directional path: the sets of the listed symmetric pairs are joined (the segment
+// index's pair kernel has united its own), the forest is flattened (launch_uf_flatten), then
+// rounds along the listed one-way pairs without pointer jumps.
+hipError_t launch_uf_union_list(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                uint32_t *parent, uint32_t n_edges_hint, hipStream_t s);
+hipError_t launch_dag_flat_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
+                                 const uint32_t *comp, uint32_t *lab, uint32_t *changed, int round,
+                                 hipStream_t s);
+// comp[v] = root of v, in place, and lab[v] = v for all n entries
+hipError_t launch_uf_flatten(uint32_t *parent, uint32_t *lab, uint32_t n, hipStream_t s);
 // label = lab[comp[v]] for the entries of ranges (null: all n), kept / root / survivor count:
 // map_labels + finalize in one pass
 // bits[i / 8] bit (i % 8) = kept[i] != 0, for i < n (ceil(n / 8) bytes written)
 hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipStream_t s);
+// find: comp[] is a forest (climb to the root), else flat
 hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
                                uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
-                               unsigned long long *counters, hipStream_t s);
+                               unsigned long long *counters, bool find, hipStream_t s);
 
 
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
                                                    void *__restrict__ fkey,
                                                    int32_t *__restrict__ thr,
                                                    uint32_t *__restrict__ label,
+                                                   uint32_t *__restrict__ lab,
                                                    unsigned long long *__restrict__ counters,
                                                    const SegDesc *__restrict__ segs, int n_seg_parts,
                                                    uint32_t *__restrict__ bin_cnt)
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
         const int32_t f = freq[i];
         thr[i] = threshold_of(percentage, f);
         label[i] = i;
+        if (lab) lab[i] = i; // (the one-way rounds' labels: smallest set that reaches this one)
         // filter key: N (100, masked by n_bits) folded onto A (000) so that the
         // filter distance never exceeds the exact one.
         const uint64_t k3 = key & ~nm;
@@ -2042,47 +2044,6 @@ __global__ __launch_bounds__(256) void jump_kernel(uint32_t *label, uint32_t n, 
 // many as the longest chain is long).  Phase 2: lab[c] = smallest set index that reaches set c,
 // propagated along the one-way pairs (rounds <= depth of the DAG).  Then label[v] = lab[comp[v]],
 // the smallest rank that reaches v: what directional.rs:30-54,78-88 removes v under.
-// atomicMin(&arr[idx], val) for the lanes with `todo`, all lanes of the wave calling together.
-// A single word takes ~90 atomics per microsecond, and hooks pile up on the roots of the big
-// trees: the lanes that share the first pending lane's target send one atomic for their
-// minimum, twice; what is left goes one by one.
-// A wave keeps the minimum for its hottest target (the leader target of its last trip: the root of
-// the giant component for most of them) in registers across the trips of its loop and sends it
-// once, when the target changes or the kernel ends.
-struct HotMin {
-    uint32_t t = 0xFFFFFFFFu, m = 0xFFFFFFFFu; // (wave-uniform)
-};
-__device__ __forceinline__ void hot_flush(uint32_t *arr, HotMin &h)
-{
-    // (a fresh look first: while this wave gathered, others have usually lowered the word)
-    if (h.t != 0xFFFFFFFFu && (threadIdx.x & 63) == 0 && __atomic_load_n(&arr[h.t], __ATOMIC_RELAXED) > h.m)
-        atomicMin(&arr[h.t], h.m);
-    h.t = 0xFFFFFFFFu;
-    h.m = 0xFFFFFFFFu;
-}
-__device__ __forceinline__ void wave_atomic_min(uint32_t *arr, uint32_t idx, uint32_t val, bool todo, HotMin &h)
-{
-    for (int pass = 0; pass < 2 && __any(todo); pass++) {
-        const int leader = __ffsll((unsigned long long)__ballot(todo)) - 1;
-        const uint32_t tgt = (uint32_t)__shfl((int)idx, leader);
-        const bool mine = todo && idx == tgt;
-        uint32_t m = mine ? val : 0xFFFFFFFFu;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
-        if (tgt == h.t) {
-            h.m = min(h.m, m);
-        } else if (pass == 0) { // the new hot target
-            hot_flush(arr, h);
-            h.t = tgt;
-            h.m = m;
-        } else if ((int)(threadIdx.x & 63) == leader && __atomic_load_n(&arr[tgt], __ATOMIC_RELAXED) > m) {
-            atomicMin(&arr[tgt], m);
-        }
-        todo = todo && !mine;
-    }
-    if (todo) atomicMin(&arr[idx], val);
-}
-
 __global__ __launch_bounds__(256) void cc_hook_kernel(const uint2 *__restrict__ edges,
                                                       const unsigned long long *counters,
                                                       uint32_t edge_cap, uint32_t *comp,
@@ -2251,14 +2212,14 @@ inline uint32_t grid_for(uint64_t work, int block, uint32_t cap = 2048)
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
-                       bool key32, void *fkey, int32_t *thr, uint32_t *label,
+                       bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
                        uint32_t *bin_cnt, hipStream_t s)
 {
     if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
     prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
                                                                      percentage, key32 ? 1 : 0, fkey, thr,
-                                                                     label, counters, segs, n_seg_parts,
+                                                                     label, lab, counters, segs, n_seg_parts,
                                                                      bin_cnt);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
                                                                      ranges ? fused_max : 0u, counters);

@@ -189,12 +189,49 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(SegArgs g, const KeyT 
 // inside the bin; the position of an entry is then bin_start + run start + an LDS counter.
 // A (block, bin) run is contiguous in the sub-bucket arrays, so the 16-byte records of a block
 // fill whole lines instead of landing one by one.
-// count the block's entries per bin of part (b0, nb) into hist[] (LDS, cleared first)
-template <typename KeyT>
-__device__ __forceinline__ void seg_block_histogram(const SegBlock &blk, const KeyT *__restrict__ fkey, int b0,
-                                                    int nb, uint32_t nbins, uint32_t *hist)
+// The parts of one pass: as many as fit the LDS counters side by side (both parts of a 12-base
+// UMI at k = 1: the keys are read once per pass).
+constexpr int SEG_PASS_PARTS = 4;
+struct SegPass {
+    int np;                        // parts in this pass
+    int b0[SEG_PASS_PARTS], nb[SEG_PASS_PARTS];
+    uint32_t nbins[SEG_PASS_PARTS], bin_off[SEG_PASS_PARTS];
+    uint32_t lds_off[SEG_PASS_PARTS]; // first counter of the part in hist[]
+    uint32_t total;                // counters of the pass
+};
+__device__ __forceinline__ SegPass seg_pass_of(const SegDesc *__restrict__ sd, int j0, int n_parts, int per_pass)
 {
-    for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) hist[b] = 0;
+    SegPass ps;
+    ps.np = min(per_pass, n_parts - j0);
+    ps.total = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_PASS_PARTS; q++) {
+        const bool on = q < ps.np;
+        ps.b0[q] = on ? sd->b0[j0 + q] : 0;
+        ps.nb[q] = on ? sd->nb[j0 + q] : 0;
+        ps.nbins[q] = on ? 1u << (2 * ps.nb[q]) : 0u;
+        ps.bin_off[q] = on ? sd->bin_off[j0 + q] : 0u;
+        ps.lds_off[q] = ps.total;
+        ps.total += ps.nbins[q];
+    }
+    return ps;
+}
+// part and bin of counter c of the pass (c < ps.total)
+__device__ __forceinline__ uint32_t seg_pass_global_bin(const SegPass &ps, uint32_t c)
+{
+    uint32_t gb = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_PASS_PARTS; q++)
+        if (q < ps.np && c >= ps.lds_off[q] && c < ps.lds_off[q] + ps.nbins[q]) gb = ps.bin_off[q] + (c - ps.lds_off[q]);
+    return gb;
+}
+
+// count the block's entries per bin of the pass's parts into hist[] (LDS, cleared first)
+template <typename KeyT>
+__device__ __forceinline__ void seg_block_histogram(const SegBlock &blk, const KeyT *__restrict__ fkey,
+                                                    const SegPass &ps, uint32_t *hist)
+{
+    for (uint32_t b = threadIdx.x; b < ps.total; b += SEG_BLOCK_THREADS) hist[b] = 0;
     __syncthreads();
     constexpr int B = 8; // loads in flight per thread
     for (uint32_t i0 = blk.start + threadIdx.x; i0 < blk.end; i0 += B * SEG_BLOCK_THREADS) {
@@ -206,7 +243,11 @@ __device__ __forceinline__ void seg_block_histogram(const SegBlock &blk, const K
         }
 #pragma unroll
         for (int q = 0; q < B; q++)
-            if (i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end) atomicAdd(&hist[seg_part_bits(key[q], b0, nb)], 1u);
+            if (i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end) {
+#pragma unroll
+                for (int j = 0; j < SEG_PASS_PARTS; j++)
+                    if (j < ps.np) atomicAdd(&hist[ps.lds_off[j] + seg_part_bits(key[q], ps.b0[j], ps.nb[j])], 1u);
+            }
     }
     __syncthreads();
 }
@@ -217,13 +258,12 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_count_lds_kernel(SegArg
     extern __shared__ uint32_t hist[];
     const SegBlock blk = g.blocks[blockIdx.x];
     const SegDesc *__restrict__ sd = g.segs + blk.seg;
-    for (int j = 0; j < g.n_parts; j++) {
-        const int b0 = sd->b0[j], nb = sd->nb[j];
-        const uint32_t nbins = 1u << (2 * nb), bin_off = sd->bin_off[j];
-        seg_block_histogram(blk, fkey, b0, nb, nbins, hist);
-        for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) {
-            const uint32_t c = hist[b];
-            if (c) atomicAdd(&g.bin_cnt[bin_off + b], c);
+    for (int j0 = 0; j0 < g.n_parts; j0 += (int)g.parts_per_pass) {
+        const SegPass ps = seg_pass_of(sd, j0, g.n_parts, (int)g.parts_per_pass);
+        seg_block_histogram(blk, fkey, ps, hist);
+        for (uint32_t c = threadIdx.x; c < ps.total; c += SEG_BLOCK_THREADS) {
+            const uint32_t cnt = hist[c];
+            if (cnt) atomicAdd(&g.bin_cnt[seg_pass_global_bin(ps, c)], cnt);
         }
         __syncthreads();
     }
@@ -238,21 +278,22 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_scatter_lds_kernel(SegA
     const SegBlock blk = g.blocks[blockIdx.x];
     const SegDesc *__restrict__ sd = g.segs + blk.seg;
     Rec *__restrict__ sub = (Rec *)g.sub_rec;
-    for (int j = 0; j < g.n_parts; j++) {
-        const int b0 = sd->b0[j], nb = sd->nb[j];
-        const uint32_t nbins = 1u << (2 * nb), bin_off = sd->bin_off[j];
-        seg_block_histogram(blk, fkey, b0, nb, nbins, hist);
-        // the block's run inside every bin it has entries for: hist[b] becomes its first position
-        for (uint32_t b = threadIdx.x; b < nbins; b += SEG_BLOCK_THREADS) {
-            const uint32_t c = hist[b];
-            if (c) hist[b] = g.bin_start[bin_off + b] + atomicAdd(&g.bin_cnt[bin_off + b], c);
+    for (int j0 = 0; j0 < g.n_parts; j0 += (int)g.parts_per_pass) {
+        const SegPass ps = seg_pass_of(sd, j0, g.n_parts, (int)g.parts_per_pass);
+        seg_block_histogram(blk, fkey, ps, hist);
+        // the block's run inside every bin it has entries for: the counter becomes its first position
+        for (uint32_t c = threadIdx.x; c < ps.total; c += SEG_BLOCK_THREADS) {
+            const uint32_t cnt = hist[c];
+            if (cnt) {
+                const uint32_t gb = seg_pass_global_bin(ps, c);
+                hist[c] = g.bin_start[gb] + atomicAdd(&g.bin_cnt[gb], cnt);
+            }
         }
         __syncthreads();
-        constexpr int B = 8;
+        constexpr int B = 4;
         for (uint32_t i0 = blk.start + threadIdx.x; i0 < blk.end; i0 += B * SEG_BLOCK_THREADS) {
             KeyT key[B];
             int32_t f[B];
-            uint32_t pos[B];
 #pragma unroll
             for (int q = 0; q < B; q++) {
                 const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
@@ -260,13 +301,20 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_scatter_lds_kernel(SegA
                 f[q] = i < blk.end ? freq[i] : 0;
             }
 #pragma unroll
-            for (int q = 0; q < B; q++)
-                pos[q] = i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end
-                             ? atomicAdd(&hist[seg_part_bits(key[q], b0, nb)], 1u) : 0u;
+            for (int j = 0; j < SEG_PASS_PARTS; j++) {
+                if (j < ps.np) {
+                    uint32_t pos[B];
 #pragma unroll
-            for (int q = 0; q < B; q++) {
-                const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
-                if (i < blk.end) sub[pos[q]] = make_rec(key[q], i, f[q]);
+                    for (int q = 0; q < B; q++)
+                        pos[q] = i0 + (uint32_t)q * SEG_BLOCK_THREADS < blk.end
+                                     ? atomicAdd(&hist[ps.lds_off[j] + seg_part_bits(key[q], ps.b0[j], ps.nb[j])], 1u)
+                                     : 0u;
+#pragma unroll
+                    for (int q = 0; q < B; q++) {
+                        const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
+                        if (i < blk.end) sub[pos[q]] = make_rec(key[q], i, f[q]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -536,7 +584,7 @@ hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *f
                             unsigned long long *counters, hipStream_t s)
 {
     if (g.n_chunks == 0 || g.n_ranges == 0) return hipSuccess;
-    const size_t lds = (size_t)g.lds_bins * sizeof(uint32_t);
+    const size_t lds = (size_t)g.lds_bins * g.parts_per_pass * sizeof(uint32_t);
     if (g.blocks) { // the histogram (else prep_kernel has counted the entries, one atomic each)
         if (key32) seg_count_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint32_t *)fkey);
         else seg_count_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint64_t *)fkey);
