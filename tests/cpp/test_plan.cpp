@@ -123,10 +123,24 @@ static void check_plan(const std::vector<uint64_t> &off, int umi_len, int k, uin
         next_bin += ch.nbins;
     }
     CHECK(next_bin == pl.seg_bins, "chunks cover the bins");
-    // task capacity: the worst case is every entry of a part in one bin
+    // task capacity: every entry of a part in one bin; all bins of 2 entries; bins of the size
+    // with the most tasks per entry (32 chunks of 64 rows at two tiles per task)
     uint64_t worst = 0;
-    for (auto &sd : pl.segs) worst += (uint64_t)pl.seg_parts * ((sd.end - sd.start - 1 + 63) / 64 + 0);
+    for (auto &sd : pl.segs) {
+        const uint64_t n = sd.end - sd.start;
+        for (int j = 0; j < pl.seg_parts; j++) {
+            const uint64_t bins = 1ull << (2 * sd.nb[j]);
+            uint64_t w = seg_tasks_of_bin((uint32_t)n);
+            w = std::max<uint64_t>(w, std::min<uint64_t>(bins, n / 2) * seg_tasks_of_bin(2));
+            const uint64_t c = 2049;
+            w = std::max<uint64_t>(w, std::min<uint64_t>(bins, n / c) * seg_tasks_of_bin((uint32_t)c) + seg_tasks_of_bin((uint32_t)(n % c)));
+            CHECK(seg_task_bound(n, bins) >= w, "task bound %" PRIu64 " < %" PRIu64, seg_task_bound(n, bins), w);
+            worst += w;
+        }
+    }
     CHECK(pl.seg_task_cap >= worst, "task capacity %" PRIu64 " < %" PRIu64, pl.seg_task_cap, worst);
+    for (uint32_t c = 0; c < 70000; c++) // the bound per sub-bucket the capacity is built on
+        CHECK(seg_tasks_of_bin(c) <= 1 + c / 7, "tasks of a sub-bucket of %u entries: %u", c, seg_tasks_of_bin(c));
     uint64_t total_pairs = 0, max_bucket = 0;
     for (uint64_t b = 0; b < nb; b++) {
         const uint64_t n = off[b + 1] - off[b];

@@ -495,10 +495,11 @@ def test_segment_index_counting_sort_and_union_variants(L, k, n_raw, n_frac):
     c = umi.Context(0)
     try:
         ref = None
-        for lds in (1, 0):
-            for unite in (1, 0):
+        for lds, unite, ckey in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (0, 0, 0)):
+            if True:
                 c.set_option("seg_lds", lds)
                 c.set_option("seg_unite", unite)
+                c.set_option("seg_ckey", ckey)  # compare keys (3 bits per base outside the bin) or filter keys
                 st = check_against_oracle(c, keys, nm, fr, off, L, k)
                 assert st["n_edges"] > 0
                 ref = ref or st

@@ -144,11 +144,14 @@ struct umi_ctx {
     uint32_t seg_min = 512;  // ... from this many entries up
     uint64_t split_min = 200000; // multi-device: a bucket at least this large that dominates the call
                                  // has its pairs split over the devices instead of the buckets
+    bool seg_ckey = true;    // its pair kernel compares 3-bit-per-base compare keys where they fit 32 bits
     bool seg_unite = true;   // its pair kernel unites symmetric pairs on the spot (batched directional path)
     bool seg_lds = true;     // counting sort of the partition through per-block LDS histograms (where
                              // every part has at most SEG_LDS_BINS bins), else one atomic per entry
     uint32_t seg_dbg = 0;
-    uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: 24 per CU, all resident at once)
+    int seg_occ[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
+    uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: all resident at once -- 24 per CU by
+                             // registers, 28 by LDS with the compare keys' leaner loop)
     // workspace
     DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, counters, boff, status, blocked;
     DevBuf plan_tables; // ranges, segment descriptors, scan chunks, popcount tile tasks: one upload
@@ -313,6 +316,7 @@ class Pipeline {
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
     uint64_t n_edges = 0;  // entries the pair kernels appended to the edge list
     uint64_t n_direct = 0; // symmetric pairs united where they were found
+    uint64_t seg_tasks_made = 0;
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
     const uint32_t *bs_perm = nullptr;
@@ -476,6 +480,7 @@ class Pipeline {
                 pl.seg_entries * (uint64_t)pl.seg_parts > 0x7FFFFFF0ull)
                 return fail(UMI_ERR_NOMEM, "segment index of this call too large (set seg_index=0)");
             const size_t m = (size_t)pl.seg_entries * (size_t)pl.seg_parts;
+            if (pl.segs.size() >= (1u << 24)) return fail(UMI_ERR_NOMEM, "too many segments in one call (set seg_index=0)");
             if ((rc = ctx->seg_bin_cnt.reserve(pl.seg_bins * 4)) || (rc = ctx->seg_bin_start.reserve(pl.seg_bins * 4)) ||
                 (rc = ctx->seg_chunk_sums.reserve(pl.seg_chunks.size() * sizeof(uint2))) ||
                 (rc = ctx->seg_tasks.reserve(pl.seg_task_cap * sizeof(SegTask))) ||
@@ -495,6 +500,8 @@ class Pipeline {
             seg.ranges = d_ranges;
             seg.n_ranges = (uint32_t)pl.ranges.size();
             seg.dbg = ctx->seg_dbg;
+            seg.umi_len = umi_len;
+            seg.use_ckey = key32 && ctx->seg_ckey && pl.seg_max_rest <= 10 ? 1u : 0u;
             if (ctx->seg_lds && pl.seg_max_bins <= SEG_LDS_BINS && !pl.seg_blocks.empty()) {
                 seg.blocks = d_seg_blocks;
                 seg.n_blocks = (uint32_t)pl.seg_blocks.size();
@@ -699,6 +706,21 @@ class Pipeline {
         return UMI_OK;
     }
 
+    // resident one-wave blocks per CU of the segment index's pair kernel variant in use (asked of the
+    // runtime once per variant and context; capped at 16, four waves per SIMD: the kernel is bound by
+    // VALU issue and by the unions' trips to memory, and config 2 takes the same time with 16, 22 or
+    // 24 blocks per CU.  The runtime's answer is an upper bound only: it says 28 for the 39-register
+    // variant, but of 26 blocks per CU the last start only when the first have left -- s_memrealtime
+    // stamps; 24 per CU are all running 1.5 us after the first -- and a late block of a persistent
+    // grid does its whole share alone)
+    uint32_t seg_occupancy()
+    {
+        const bool has_n = d_nmask != nullptr, ck = seg.use_ckey != 0;
+        int &slot = ctx->seg_occ[key32 ? 1 : 0][has_n ? 1 : 0][ck ? 1 : 0];
+        if (!slot) slot = seg_pair_blocks_per_cu(key32, has_n, ck);
+        return (uint32_t)slot;
+    }
+
     // all pair kernels of the call, largest work first (nothing waits on the host in here)
     int enqueue_pairs(uint64_t ovf_cap)
     {
@@ -724,7 +746,7 @@ class Pipeline {
         a.n_entries = n;
         if (pl.seg_parts) { // the large buckets' sub-buckets: persistent one-wave blocks
             const uint32_t blocks = std::max(1u, (uint32_t)std::min<uint64_t>(
-                pl.seg_task_cap, ctx->seg_blocks ? ctx->seg_blocks : (uint64_t)ctx->n_cus * 24));
+                pl.seg_task_cap, ctx->seg_blocks ? ctx->seg_blocks : (uint64_t)ctx->n_cus * std::min(16u, seg_occupancy())));
             int rc;
             if ((rc = ctx->seg_priv_edges.reserve((size_t)blocks * SEG_PRIV_CAP * sizeof(uint2))) ||
                 (rc = ctx->seg_priv_cnt.reserve((size_t)blocks * 4)) ||
@@ -734,6 +756,7 @@ class Pipeline {
             seg.priv_dist = ctx->seg_priv_dist.as<uint8_t>();
             seg.priv_cnt = ctx->seg_priv_cnt.as<uint32_t>();
             seg.uf_parent = one_sync() && ctx->seg_unite ? ctx->label.as<uint32_t>() : nullptr;
+
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             st.n_pair_launches += 1;
         }
@@ -769,6 +792,7 @@ class Pipeline {
     {
         n_edges = ctx->h_counters[CNT_EDGES];
         n_direct = ctx->h_counters[CNT_UF_DIRECT];
+        seg_tasks_made = ctx->h_counters[CNT_SEG_TASKS];
         st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
         st.n_pairs_evaluated = pl.n_pairs_eval + ctx->h_counters[CNT_SEG_PAIRS];
         if (!pl.tab_rows.empty()) // the table kernel walks only the column tiles its scan kept
@@ -824,6 +848,8 @@ class Pipeline {
             }
             if (prof && !redo) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             note_pair_counters();
+            if (pl.seg_parts && seg_tasks_made > seg.task_cap)
+                return fail(UMI_ERR_HIP, "internal: %llu segment tasks for a list of %u", (unsigned long long)seg_tasks_made, seg.task_cap);
             if (!redo && n_edges <= cap) break;
             if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
             if (n_edges > cap) {
@@ -875,6 +901,8 @@ class Pipeline {
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
             if ((rc = read_control())) return rc;
             note_pair_counters();
+            if (pl.seg_parts && seg_tasks_made > seg.task_cap)
+                return fail(UMI_ERR_HIP, "internal: %llu segment tasks for a list of %u", (unsigned long long)seg_tasks_made, seg.task_cap);
             if (n_edges <= cap || !have_pairs) break;
             if (attempt >= 3) return fail(UMI_ERR_HIP, "edge list overflow persists");
             // the list was too short: the exact count is known now
@@ -1468,6 +1496,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->two_phase = (int)value;
     } else if (!strcmp(name, "seg_index")) {
         ctx->seg_index = value != 0;
+    } else if (!strcmp(name, "seg_ckey")) {
+        ctx->seg_ckey = value != 0;
     } else if (!strcmp(name, "seg_unite")) {
         ctx->seg_unite = value != 0;
     } else if (!strcmp(name, "seg_lds")) {

@@ -90,7 +90,9 @@ struct SegRec32 {
     uint32_t key; // filter key
     uint32_t idx; // entry index
     int32_t freq;
-    uint32_t pad;
+    uint32_t ckey; // compare key of the part the record is filed under: the bases outside the bin's own
+                   // (those agree inside a sub-bucket), 3 bits each in the reference's code (N folded
+                   // onto A), so that bases differing = popcount(a ^ b) / 2; 0 where it does not fit
 };
 struct SegRec64 {
     uint64_t key;
@@ -103,12 +105,41 @@ struct SegScanChunk {
     uint32_t seg, part;
 };
 constexpr uint32_t SEG_SCAN_CHUNK = 1024;
-// One unit of sub-bucket work: rows [row0, min(row0 + 64, end)) against the later entries of the
-// sub-bucket, columns (row, end), all positions in the sub-bucket arrays.
+// One unit of sub-bucket work: rows [row0, min(row0 + 64, end)) against columns [col0,
+// min(end, col0 + 64 * 2^e)) of the same sub-bucket (which ends at `end`), all positions in the
+// sub-bucket arrays; only pairs with row < column count.  A 64-row chunk faces nt - t tiles of 64
+// later entries (t = its number, nt = the sub-bucket's chunks).  Up to 16 chunks (1025 entries)
+// every tile is a task of its own, e = 0: tasks of one size, which the pair kernel's persistent
+// waves can be dealt statically (whole chunks of 1..nt tiles each left the slowest wave of config
+// 2 with 1.7 times the average; drawing tasks from counters costs a returning atomic's round trip
+// per task, more than a tile).  Beyond that e grows so that a chunk never gives more than 16 tasks.
 struct SegTask {
     uint32_t row0, end;
-    uint32_t seg, part;
+    uint32_t col0;
+    uint32_t where; // segment | part << 24 | e << 28
 };
+#if defined(__HIPCC__)
+#define UMIHIP_HD __host__ __device__
+#else
+#define UMIHIP_HD
+#endif
+UMIHIP_HD inline uint32_t seg_chunks_of(uint32_t c) { return c >= 2 ? (c - 1 + 63) / 64 : 0u; } // nt
+UMIHIP_HD inline uint32_t seg_span_log2(uint32_t nt)
+{
+    uint32_t e = 0;
+    while (((nt + 15) / 16) > (1u << e)) e++;
+    return e;
+}
+// tasks of a sub-bucket of c entries: sum over its chunks t of ceil((nt - t) / span)
+UMIHIP_HD inline uint32_t seg_tasks_of_bin(uint32_t c)
+{
+    const uint32_t nt = seg_chunks_of(c);
+    if (nt == 0) return 0;
+    const uint32_t span = 1u << seg_span_log2(nt), q = nt / span, r = nt % span;
+    return span * (q * (q + 1) / 2) + r * (q + 1);
+}
+// ... and an upper bound for a part of n entries over `bins` bins (seg_tasks_of_bin(c) <= 1 + c / 7)
+inline uint64_t seg_task_bound(uint64_t n, uint64_t bins) { return n / 7 + (bins < n / 2 ? bins : n / 2) + 64; }
 // One block of the counting sort's LDS path: entries [start, end) of segment `seg`
 // (<= SEG_BLOCK_ENTRIES of them).  The block counts its entries per bin in LDS and touches a bin's
 // global word once (count pass: one add; scatter pass: one returning add that reserves the
@@ -205,6 +236,9 @@ struct SegArgs {
     // directional batched path: parent array of the union-find (= label[]).  A pair permitted in both
     // directions is united where it is found instead of going through the edge list (null: listed)
     uint32_t *uf_parent;
+    int umi_len;
+    uint32_t use_ckey; // 32-bit keys: the pair kernel compares the records' compare keys (every part of
+                       // every segment leaves at most 10 bases outside its bins)
     uint32_t dbg; // tuning experiments only (ctx option seg_dbg): 1 drop the queued hits, 2 skip the column loop
 };
 // exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];
@@ -214,6 +248,7 @@ hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *f
 constexpr uint32_t SEG_PRIV_CAP = 512; // = the LDS edge stage of a block
 // all pairs inside the sub-buckets: filter + exact check + edge emission (percentage: thresholds
 // are recomputed from the staged freq).  part/n_parts: a multi-GPU split takes every n_parts-th task.
+int seg_pair_blocks_per_cu(bool key32, bool has_n, bool ckey);
 hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
                             uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s);
 

@@ -43,6 +43,7 @@ struct Plan {
     std::vector<SegScanChunk> seg_chunks;
     std::vector<SegBlock> seg_blocks; // entry blocks of the counting sort's LDS path
     uint32_t seg_max_bins = 0;        // most bins any part of any segment has
+    int seg_max_rest = 0;             // most bases any part of any segment leaves outside its bins
     int seg_parts = 0;           // k + 1 (0: no segment in this call)
     uint64_t seg_entries = 0;    // entries of all segments (M): each part's sub-bucket order holds M
     uint64_t seg_bins = 0;       // bins of all parts of all segments
@@ -212,8 +213,8 @@ inline void plan_segment(Plan &pl, uint64_t s, uint64_t e, int umi_len, int k, b
                                      seg, (uint32_t)j});
         pl.seg_bins += bins;
         pl.seg_max_bins = std::max<uint32_t>(pl.seg_max_bins, (uint32_t)std::min<uint64_t>(bins, 0xFFFFFFFFull));
-        // a sub-bucket of c >= 2 entries gives ceil((c - 1) / 64) <= c / 64 + 1 tasks
-        pl.seg_task_cap += n / 64 + std::min<uint64_t>(bins, n / 2) + 1;
+        pl.seg_max_rest = std::max(pl.seg_max_rest, umi_len - nb);
+        pl.seg_task_cap += seg_task_bound(n, bins);
     }
     pl.seg_entries += n;
     for (uint64_t q = s; q < e; q += SEG_BLOCK_ENTRIES)
@@ -230,6 +231,7 @@ inline void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t 
     pl.seg_chunks.clear();
     pl.seg_blocks.clear();
     pl.seg_max_bins = 0;
+    pl.seg_max_rest = 0;
     pl.seg_parts = 0;
     pl.seg_entries = pl.seg_bins = pl.seg_task_cap = 0;
     const bool seg_ok = seg_min > 0 && seg_index_applies(umi_len, k);

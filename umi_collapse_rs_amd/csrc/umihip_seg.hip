@@ -22,10 +22,7 @@ namespace {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_PER_THREAD = SEG_SCAN_CHUNK / SCAN_THREADS; // 16 bins per thread
 
-__device__ __forceinline__ uint32_t tasks_of_bin(uint32_t c)
-{
-    return c >= 2 ? (c - 1 + 63) / 64 : 0u; // the last entry of a sub-bucket has no later column
-}
+__device__ __forceinline__ uint32_t tasks_of_bin(uint32_t c) { return seg_tasks_of_bin(c); }
 
 // (entries, tasks) per scan chunk
 __global__ __launch_bounds__(SCAN_THREADS) void seg_scan_reduce_kernel(SegArgs g)
@@ -130,13 +127,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void seg_scan_apply_kernel(SegArgs g,
         if (b < ch.nbins) {
             g.bin_start[ch.bin0 + b] = off.x;
             g.bin_cnt[ch.bin0 + b] = 0;
-            const uint32_t nt = tasks_of_bin(c[q]);
-            for (uint32_t t = 0; t < nt; t++)
-                if (off.y + t < g.task_cap)
-                    g.tasks[off.y + t] = SegTask{off.x + 64u * t, off.x + c[q], ch.seg, ch.part};
+            const uint32_t nt = seg_chunks_of(c[q]), e = seg_span_log2(nt), span = 1u << e;
+            const uint32_t where = ch.seg | (ch.part << 24) | (e << 28);
+            uint32_t ti = off.y;
+            for (uint32_t t = 0; t < nt; t++) {
+                const uint32_t row0 = off.x + 64u * t;
+                for (uint32_t sp = 0; sp < nt - t; sp += span, ti++)
+                    if (ti < g.task_cap) g.tasks[ti] = SegTask{row0, off.x + c[q], row0 + 1u + 64u * sp, where};
+            }
+            const uint32_t n_bin_tasks = ti - off.y;
             pairs += (unsigned long long)c[q] * (c[q] ? c[q] - 1 : 0) / 2;
             off.x += c[q];
-            off.y += nt;
+            off.y += n_bin_tasks;
         }
     }
     // (64-bit sum over the block, one atomic)
@@ -154,8 +156,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void seg_scan_apply_kernel(SegArgs g,
 template <typename KeyT> struct SegRecOf;
 template <> struct SegRecOf<uint32_t> { using type = SegRec32; };
 template <> struct SegRecOf<uint64_t> { using type = SegRec64; };
-__device__ __forceinline__ SegRec32 make_rec(uint32_t key, uint32_t idx, int32_t freq) { return SegRec32{key, idx, freq, 0u}; }
-__device__ __forceinline__ SegRec64 make_rec(uint64_t key, uint32_t idx, int32_t freq) { return SegRec64{key, idx, freq}; }
+// The 3-bit code of every base of a 2-bit filter key (A 000, T 101, C 110, G 011 as in
+// src/utils/read.rs:23-31; the filter key holds the low two bits, the third is their xor): any two
+// different bases differ in exactly two bits.  umi_len <= 16: 48 bits.
+__device__ __forceinline__ uint64_t expand3(uint32_t fkey, int umi_len)
+{
+    uint64_t e = 0;
+    for (int b = 0; b < umi_len; b++) {
+        const uint32_t c = (fkey >> (2 * b)) & 3u;
+        e |= (uint64_t)(c | (((c >> 1) ^ c) & 1u) << 2) << (3 * b);
+    }
+    return e;
+}
+// ... without the nb bases from b0 on (the bin's own); 0 if more than 10 bases are left
+__device__ __forceinline__ uint32_t compare_key(uint64_t e3, int b0, int nb, int umi_len)
+{
+    if (umi_len - nb > 10) return 0u;
+    const uint64_t lo = e3 & ((1ull << (3 * b0)) - 1ull);
+    const uint64_t hi = e3 >> (3 * (b0 + nb));
+    return (uint32_t)(lo | (hi << (3 * b0)));
+}
+__device__ __forceinline__ SegRec32 make_rec(uint32_t key, uint32_t idx, int32_t freq, uint32_t ckey) { return SegRec32{key, idx, freq, ckey}; }
+__device__ __forceinline__ SegRec64 make_rec(uint64_t key, uint32_t idx, int32_t freq, uint32_t) { return SegRec64{key, idx, freq}; }
+__device__ __forceinline__ uint64_t expand3(uint64_t, int) { return 0ull; }
 
 // every entry of a segment to its position in each part's sub-bucket order (the order inside a
 // sub-bucket is arbitrary: all its pairs are evaluated, and a pair is reported with its entry
@@ -171,11 +194,12 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(SegArgs g, const KeyT 
     Rec *__restrict__ sub = (Rec *)g.sub_rec;
     for (uint32_t i = r.start + threadIdx.x; i < r.end; i += blockDim.x) {
         const KeyT key = fkey[i];
-        const Rec rec = make_rec(key, i, freq[i]);
+        const int32_t f = freq[i];
+        const uint64_t e3 = g.use_ckey ? expand3(key, g.umi_len) : 0ull;
         for (int j = 0; j < g.n_parts; j++) {
             const uint32_t b = sd->bin_off[j] + seg_part_bits(key, sd->b0[j], sd->nb[j]);
             const uint32_t pos = g.bin_start[b] + atomicAdd(&g.bin_cnt[b], 1u);
-            sub[pos] = rec;
+            sub[pos] = make_rec(key, i, f, g.use_ckey ? compare_key(e3, sd->b0[j], sd->nb[j], g.umi_len) : 0u);
         }
     }
 }
@@ -300,6 +324,9 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_scatter_lds_kernel(SegA
                 key[q] = i < blk.end ? fkey[i] : KeyT(0);
                 f[q] = i < blk.end ? freq[i] : 0;
             }
+            uint64_t e3[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) e3[q] = g.use_ckey ? expand3(key[q], g.umi_len) : 0ull;
 #pragma unroll
             for (int j = 0; j < SEG_PASS_PARTS; j++) {
                 if (j < ps.np) {
@@ -312,7 +339,9 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_scatter_lds_kernel(SegA
 #pragma unroll
                     for (int q = 0; q < B; q++) {
                         const uint32_t i = i0 + (uint32_t)q * SEG_BLOCK_THREADS;
-                        if (i < blk.end) sub[pos[q]] = make_rec(key[q], i, f[q]);
+                        if (i < blk.end)
+                            sub[pos[q]] = make_rec(key[q], i, f[q],
+                                                   g.use_ckey ? compare_key(e3[q], ps.b0[j], ps.nb[j], g.umi_len) : 0u);
                     }
                 }
             }
@@ -356,12 +385,135 @@ __device__ __forceinline__ bool within_k(uint64_t z, int k)
 // again (L2), the dedupe rule (a pair that shares an earlier part's bin was reported there), the
 // exact distance with the reference's arithmetic where keys carry N, the freq predicate of the
 // mode, and the edge goes to the block's LDS stage.
-template <typename KeyT, bool HAS_N>
+// the key the column loop compares: the record's filter key, or (CK) its compare key
+template <bool CK> __device__ __forceinline__ uint32_t loop_key(const SegRec32 &r) { return CK ? r.ckey : r.key; }
+template <bool CK> __device__ __forceinline__ uint64_t loop_key(const SegRec64 &r) { return r.key; }
+// at most k bases differ
+template <bool CK> __device__ __forceinline__ bool loop_within_k(uint32_t z, int k)
+{
+    return CK ? __builtin_popcount(z) <= 2 * k : within_k(z, k);
+}
+template <bool CK> __device__ __forceinline__ bool loop_within_k(uint64_t z, int k) { return within_k(z, k); }
+
+// Columns J, J-1, J-2, J-3 of the tile (keys in the lanes of ky) against this lane's row x: the
+// outcome "at most k bases differ" of each is shifted into h from below, highest column first.
+// Compare keys (CK; lim2 = 2 k, wave-uniform): five instructions per column -- broadcast, xor,
+// popcount, compare, add-with-carry -- written out, four columns interleaved so that no broadcast
+// or compare mask is read within two instructions of the VALU instruction that wrote it (gfx950:
+// two wait states between a VALU write of an SGPR or VCC and a VALU read of it -- the compiler
+// covers them with s_nop, inline asm has to keep the distance itself; the compiler's own
+// select-and-or accumulation takes two to three instructions instead of the add).
+template <bool CK, int J> __device__ __forceinline__ uint32_t four_columns(uint32_t h, uint32_t x, uint32_t ky, int k, uint32_t lim2)
+{
+    if (CK) {
+        uint32_t s0, s1, s2, s3, t0, t1, t2, t3;
+        unsigned long long p0, p1, p2, p3; // the compares' lane masks, each its own SGPR pair
+        asm("v_readlane_b32 %1, %14, %16\n\t"
+            "v_readlane_b32 %2, %14, %17\n\t"
+            "v_readlane_b32 %3, %14, %18\n\t"
+            "v_readlane_b32 %4, %14, %19\n\t"
+            "v_xor_b32_e32 %5, %1, %13\n\t"
+            "v_xor_b32_e32 %6, %2, %13\n\t"
+            "v_xor_b32_e32 %7, %3, %13\n\t"
+            "v_xor_b32_e32 %8, %4, %13\n\t"
+            "v_bcnt_u32_b32 %5, %5, 0\n\t"
+            "v_bcnt_u32_b32 %6, %6, 0\n\t"
+            "v_bcnt_u32_b32 %7, %7, 0\n\t"
+            "v_bcnt_u32_b32 %8, %8, 0\n\t"
+            "v_cmp_ge_u32_e64 %9, %15, %5\n\t"
+            "v_cmp_ge_u32_e64 %10, %15, %6\n\t"
+            "v_cmp_ge_u32_e64 %11, %15, %7\n\t"
+            "v_cmp_ge_u32_e64 %12, %15, %8\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %9\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %10\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %11\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %12"
+            : "+v"(h), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+              "=&s"(p0), "=&s"(p1), "=&s"(p2), "=&s"(p3)
+            : "v"(x), "v"(ky), "s"(lim2), "n"(J), "n"(J - 1), "n"(J - 2), "n"(J - 3)
+            : "vcc");
+        return h;
+    }
+#pragma unroll
+    for (int j = J; j > J - 4; j--) h = h + h + (within_k(x ^ readlane_key(ky, j), k) ? 1u : 0u);
+    return h;
+}
+template <bool CK, int J> __device__ __forceinline__ uint32_t four_columns(uint32_t h, uint64_t x, uint64_t ky, int k, uint32_t)
+{
+#pragma unroll
+    for (int j = J; j > J - 4; j--) h = h + h + (within_k(x ^ readlane_key(ky, j), k) ? 1u : 0u);
+    return h;
+}
+// columns BASE + 31 .. BASE of the tile
+template <bool CK, int BASE, typename KeyT>
+__device__ __forceinline__ uint32_t columns32(KeyT x, KeyT ky, int k, uint32_t lim2)
+{
+    uint32_t h = 0;
+    h = four_columns<CK, BASE + 31>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 27>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 23>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 19>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 15>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 11>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 7>(h, x, ky, k, lim2);
+    h = four_columns<CK, BASE + 3>(h, x, ky, k, lim2);
+    return h;
+}
+
+// ILP unions per lane, their steps interleaved: a union is a chain of dependent scattered accesses
+// (a load or a compare-and-swap per step, each a trip to the memory side), and a wave waits for
+// the longest chain among its lanes; with ILP chains per lane in flight the trips of the others
+// ride along.  Same algorithm as uf_union, step for step.
+template <int ILP>
+__device__ __forceinline__ void uf_union_multi(uint32_t *parent, uint32_t (&u)[ILP], uint32_t (&v)[ILP], bool (&act)[ILP])
+{
+    uint32_t pu[ILP], pv[ILP];
+#pragma unroll
+    for (int s = 0; s < ILP; s++) {
+        pu[s] = act[s] ? ld_parent(&parent[u[s]]) : 0u;
+        pv[s] = act[s] ? ld_parent(&parent[v[s]]) : 0u;
+    }
+    for (;;) {
+        bool cas[ILP], any = false;
+#pragma unroll
+        for (int s = 0; s < ILP; s++) {
+            act[s] = act[s] && pu[s] != pv[s];
+            if (act[s] && pu[s] < pv[s]) { // u is the side whose parent is the larger
+                uint32_t t = u[s]; u[s] = v[s]; v[s] = t;
+                t = pu[s]; pu[s] = pv[s]; pv[s] = t;
+            }
+            cas[s] = act[s] && u[s] == pu[s]; // a root, as far as was seen: under the other side's parent
+            any = any || act[s];
+        }
+        if (!any) break;
+        uint32_t r[ILP];
+#pragma unroll
+        for (int s = 0; s < ILP; s++) // (all of the step's accesses go out before any is waited for)
+            r[s] = !act[s] ? 0u : cas[s] ? atomicCAS(&parent[u[s]], u[s], pv[s]) : ld_parent(&parent[pu[s]]);
+#pragma unroll
+        for (int s = 0; s < ILP; s++) {
+            if (!act[s]) continue;
+            if (cas[s]) {
+                if (r[s] == u[s]) act[s] = false; // hooked
+                else pu[s] = r[s];                // hooked by somebody else meanwhile: that is where it points now
+            } else { // climbed
+                u[s] = pu[s];
+                pu[s] = r[s];
+            }
+        }
+    }
+}
+
+template <typename KeyT, bool HAS_N, bool CK>
 __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, float percentage,
                                                       uint32_t part, uint32_t n_parts)
 {
     using Rec = typename SegRecOf<KeyT>::type;
-    constexpr uint32_t HITQ = 128; // a drain starts at 64 queued hits; one round adds at most 64
+    constexpr int ILP = 1;                      // queued hits a lane works off together (more: fewer, longer
+                                                // drains, and a wave of config 2 queues under 200 hits in all --
+                                                // the unions would all wait for the end of the kernel)
+    constexpr uint32_t DRAIN_AT = 64 * ILP;     // a drain starts at this many queued hits ...
+    constexpr uint32_t HITQ = DRAIN_AT + 64;    // ... and one round adds at most 64
     __shared__ EdgeStage stage;
     __shared__ uint2 hitq[HITQ]; // (row position, column position) in the sub-bucket arrays
     const int lane = threadIdx.x;
@@ -375,6 +527,7 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
     __syncthreads();
     const uint32_t n_tasks = (uint32_t)min((unsigned long long)g.task_cap, a.counters[CNT_SEG_TASKS]);
     unsigned int n_cand = 0, n_direct = 0;
+    const uint32_t lim2 = (uint32_t)__builtin_amdgcn_readfirstlane(2 * a.k);
     // masks of the bins of the parts before the task's own: a pair that shares one of them was
     // reported there.  Kept while the tasks stay in one (segment, part): nearly always.
     KeyT dup_mask[SEG_MAX_PARTS - 1];
@@ -383,137 +536,173 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
     uint32_t have_seg = SEG_NONE, have_part = 0;
     uint32_t nq = 0; // queued hits (wave-uniform); the queue outlives a task
 
-    // the queued hits, one per lane
+    // The queued hits, ILP per lane at a time: both records again (L2), the dedupe rule (a pair
+    // that shares an earlier part's bin was reported there), the exact distance with the
+    // reference's arithmetic where keys carry N, the freq predicate of the mode; a one-way pair
+    // goes to the block's LDS stage, a symmetric one is united on the spot (batched directional
+    // path) or staged as well.
     auto drain = [&]() {
         __builtin_amdgcn_wave_barrier();
         if (g.dbg & 1u) nq = 0;
-        for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
-            const uint32_t q = q0 + (uint32_t)lane;
-            if (q < nq) {
-                const uint2 h = hitq[q];
-                const Rec ra = sub[h.x], cb = sub[h.y];
-                const KeyT z = ra.key ^ cb.key;
+        for (uint32_t q0 = 0; q0 < nq; q0 += 64 * ILP) {
+            Rec ra[ILP], cb[ILP];
+            bool live[ILP];
+#pragma unroll
+            for (int s = 0; s < ILP; s++) {
+                const uint32_t q = q0 + (uint32_t)s * 64u + (uint32_t)lane;
+                live[s] = q < nq;
+                const uint2 h = live[s] ? hitq[q] : make_uint2(0u, 0u);
+                ra[s] = sub[live[s] ? h.x : 0u]; // (position 0 exists: the call has a segment)
+                cb[s] = sub[live[s] ? h.y : 0u];
+            }
+            uint32_t uu[ILP], uv[ILP];
+            bool unite[ILP];
+#pragma unroll
+            for (int s = 0; s < ILP; s++) {
+                unite[s] = false;
+                uu[s] = uv[s] = 0;
+                if (!live[s]) continue;
+                const KeyT z = ra[s].key ^ cb[s].key;
                 bool ok = true;
 #pragma unroll
                 for (int p = 0; p < SEG_MAX_PARTS - 1; p++)
                     ok = ok && (dup_mask[p] == KeyT(0) || (z & dup_mask[p]) != KeyT(0));
-                if (ok) {
-                    // entry indices in rank order (src/algo/directional.rs:67-72)
-                    const bool sw = cb.idx < ra.idx;
-                    const uint32_t gi = sw ? cb.idx : ra.idx, gj = sw ? ra.idx : cb.idx;
-                    const int32_t fi = sw ? cb.freq : ra.freq, fj = sw ? ra.freq : cb.freq;
-                    int dist;
-                    if (HAS_N) { // bitset.rs:85-87 (one word) and utils/mod.rs:25
-                        const uint64_t ka = a.keys[gi], kb = a.keys[gj];
-                        const uint64_t xn = a.nmask[gi] ^ a.nmask[gj];
-                        dist = (__builtin_popcountll(xn | (ka ^ kb)) - __builtin_popcountll(xn) / 3) / 2;
-                    } else { // no N in the call: the filter key is the key
-                        dist = filter_key_distance(ra.key, cb.key);
+                if (!ok) continue;
+                // entry indices in rank order (src/algo/directional.rs:67-72)
+                const bool sw = cb[s].idx < ra[s].idx;
+                const uint32_t gi = sw ? cb[s].idx : ra[s].idx, gj = sw ? ra[s].idx : cb[s].idx;
+                const int32_t fi = sw ? cb[s].freq : ra[s].freq, fj = sw ? ra[s].freq : cb[s].freq;
+                int dist;
+                if (HAS_N) { // bitset.rs:85-87 (one word) and utils/mod.rs:25
+                    const uint64_t ka = a.keys[gi], kb = a.keys[gj];
+                    const uint64_t xn = a.nmask[gi] ^ a.nmask[gj];
+                    dist = (__builtin_popcountll(xn | (ka ^ kb)) - __builtin_popcountll(xn) / 3) / 2;
+                } else { // no N in the call: the filter key is the key
+                    dist = filter_key_distance(ra[s].key, cb[s].key);
+                }
+                n_cand++;
+                if (dist > a.k || (g.dbg & 4u)) continue;
+                if (a.mode == MODE_NEIGHBOURS) {
+                    emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, true);
+                    continue;
+                }
+                bool fwd, bwd;
+                if (a.mode == MODE_DIRECTIONAL) { // naive.rs:31 under directional.rs:38-39
+                    fwd = fj <= threshold_of(percentage, fi);
+                    bwd = fi <= threshold_of(percentage, fj);
+                } else { // adjacency.rs:56: a root only ever sees entries of larger rank
+                    fwd = fj <= a.adj_max_freq;
+                    bwd = false;
+                }
+                if (fwd && bwd) {
+                    if (g.uf_parent) { // reachability inside such a set is symmetric: one set
+                        unite[s] = true;
+                        uu[s] = gi;
+                        uv[s] = gj;
+                        n_direct++;
+                    } else {
+                        emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi | SYM_FLAG, gj, dist, false);
                     }
-                    n_cand++;
-                    if (dist <= a.k && !(g.dbg & 4u)) {
-                        if (a.mode == MODE_NEIGHBOURS) {
-                            emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, true);
-                        } else {
-                            bool fwd, bwd;
-                            if (a.mode == MODE_DIRECTIONAL) { // naive.rs:31 under directional.rs:38-39
-                                fwd = fj <= threshold_of(percentage, fi);
-                                bwd = fi <= threshold_of(percentage, fj);
-                            } else { // adjacency.rs:56: a root only ever sees entries of larger rank
-                                fwd = fj <= a.adj_max_freq;
-                                bwd = false;
-                            }
-                            if (fwd && bwd) {
-                                if (g.uf_parent) { // reachability inside such a set is symmetric: one set
-                                    uf_union(g.uf_parent, gi, gj);
-                                    n_direct++;
-                                } else {
-                                    emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi | SYM_FLAG, gj, dist, false);
-                                }
-                            }
-                            else if (fwd)
-                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, false);
-                            else if (bwd)
-                                emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gj, gi, dist, false);
-                        }
-                    }
+                } else if (fwd) {
+                    emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, false);
+                } else if (bwd) {
+                    emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gj, gi, dist, false);
                 }
             }
+            if (g.uf_parent) uf_union_multi<ILP>(g.uf_parent, uu, uv, unite);
+            __builtin_amdgcn_wave_barrier();
+            // (the stage is this wave's alone: its fill level is wave-uniform; a pass adds at most 64 * ILP)
+            static_assert(64 * ILP <= EDGE_BUF / 4, "a pass must fit the stage's last quarter");
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)&stage.count) >= (unsigned int)EDGE_BUF * 3u / 4u)
+                flush_edges<64>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, false);
         }
         nq = 0;
         __builtin_amdgcn_wave_barrier();
-        // (the stage is this wave's alone: its fill level is wave-uniform)
-        if ((unsigned int)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)&stage.count) >= (unsigned int)EDGE_BUF * 3u / 4u)
-            flush_edges<64>(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, with_dist, false);
     };
 
-    // The loads run ahead of their use: the next task's record is fetched while this one is
-    // worked on, the next 64 columns while these are.
+    // Tasks are dealt statically, task t to block t mod the grid, and two stages run ahead of the
+    // task in hand: the record of the task after next and the row and column keys of the next one
+    // are under way while this one's columns are walked (a task is one 64 x 64 tile: a few hundred
+    // instructions, less than one trip to memory).
+    const uint32_t stride = gridDim.x;
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    auto task_keys = [&](const uint4 &w, bool valid, KeyT &xk, KeyT &ck) {
+        const uint32_t row0 = __builtin_amdgcn_readfirstlane(w.x), end = __builtin_amdgcn_readfirstlane(w.y);
+        const uint32_t col0 = __builtin_amdgcn_readfirstlane(w.z);
+        xk = pad_row<KeyT>();
+        ck = pad_col<KeyT>();
+        if (valid && row0 + (uint32_t)lane < end && lane < 64) xk = loop_key<CK>(sub[row0 + (uint32_t)lane]);
+        if (valid && col0 + (uint32_t)lane < end) ck = loop_key<CK>(sub[col0 + (uint32_t)lane]);
+    };
     uint32_t t = blockIdx.x;
-    uint4 tw = t < n_tasks ? task_words[t] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 tw = t < n_tasks ? task_words[t] : none;
+    uint4 tw1 = t + stride < n_tasks && t + stride > t ? task_words[t + stride] : none;
+    KeyT x, ky;
+    task_keys(tw, t < n_tasks, x, ky);
     while (t < n_tasks) {
-        const uint32_t t_next = t + gridDim.x;
-        const uint4 tw_next = t_next < n_tasks ? task_words[t_next] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t t1 = t + stride, t2 = t1 + stride;
+        const bool has1 = t1 < n_tasks && t1 > t, has2 = has1 && t2 < n_tasks && t2 > t1;
+        const uint4 tw2 = has2 ? task_words[t2] : none;
+        KeyT x1, ky1;
+        task_keys(tw1, has1, x1, ky1);
         const uint32_t row0 = __builtin_amdgcn_readfirstlane(tw.x);
         const uint32_t end = __builtin_amdgcn_readfirstlane(tw.y);
-        const uint32_t seg = __builtin_amdgcn_readfirstlane(tw.z);
-        const uint32_t my_part = __builtin_amdgcn_readfirstlane(tw.w);
-        t = t_next;
-        tw = tw_next;
+        const uint32_t col0 = __builtin_amdgcn_readfirstlane(tw.z);
+        const uint32_t where = __builtin_amdgcn_readfirstlane(tw.w);
+        const uint32_t seg = where & 0xFFFFFFu, my_part = (where >> 24) & 15u;
+        const uint32_t col1 = (uint32_t)min((unsigned long long)end, (unsigned long long)col0 + (64ull << (where >> 28)));
         // A multi-GPU split hands out whole sub-buckets: the order inside one differs from rank to
         // rank (the scatter's atomics), its extent does not -- `end` names the sub-bucket.
-        if (n_parts > 1 && (((end ^ (end >> 7)) * 0x9E3779B1u) >> 8) % n_parts != part) continue;
-        const uint32_t n_rows = min(64u, end - row0);
-        const uint32_t r = row0 + (uint32_t)lane;
-        KeyT x = pad_row<KeyT>();
-        if ((uint32_t)lane < n_rows) x = sub[r].key;
-        KeyT ky = pad_col<KeyT>();
-        if (row0 + 1 + (uint32_t)lane < end) ky = sub[row0 + 1 + (uint32_t)lane].key;
-        if (seg != have_seg || my_part != have_part) { // (wave-uniform)
-            if (nq) drain(); // the queued hits belong to the masks in hand
-            const SegDesc *__restrict__ sd = g.segs + seg;
+        const bool mine = !(n_parts > 1 && (((end ^ (end >> 7)) * 0x9E3779B1u) >> 8) % n_parts != part);
+        if (mine) {
+            const uint32_t n_rows = min(64u, end - row0);
+            const uint32_t r = row0 + (uint32_t)lane;
+            if (seg != have_seg || my_part != have_part) { // (wave-uniform)
+                if (nq) drain(); // the queued hits belong to the masks in hand
+                const SegDesc *__restrict__ sd = g.segs + seg;
 #pragma unroll
-            for (int j = 0; j < SEG_MAX_PARTS - 1; j++)
-                dup_mask[j] = (uint32_t)j < my_part ? (KeyT)sd->mask[j] : KeyT(0);
-            have_seg = seg;
-            have_part = my_part;
-        }
-
-        for (uint32_t c0 = row0 + 1; c0 < end; c0 += 64) {
-            // the next 64 columns, under way while these are walked
-            const uint32_t cn_pos = c0 + 64u + (uint32_t)lane;
-            KeyT kn = pad_col<KeyT>();
-            if (cn_pos < end) kn = sub[cn_pos].key;
-            const uint32_t nc = (g.dbg & 2u) ? 0u : min(64u, end - c0);
-            uint32_t hlo = 0, hhi = 0; // bit j: this lane's row is within k of column j of the tile
-#pragma unroll
-            for (int j = 0; j < 32; j++)
-                hlo |= within_k(x ^ readlane_key(ky, j), a.k) ? (1u << j) : 0u;
-            if (nc > 32) {
-#pragma unroll
-                for (int j = 0; j < 32; j++)
-                    hhi |= within_k(x ^ readlane_key(ky, 32 + j), a.k) ? (1u << j) : 0u;
+                for (int j = 0; j < SEG_MAX_PARTS - 1; j++)
+                    dup_mask[j] = (uint32_t)j < my_part ? (KeyT)sd->mask[j] : KeyT(0);
+                have_seg = seg;
+                have_part = my_part;
             }
-            unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
-            // the columns this lane's row may pair with: inside the tile, and behind the row
-            // (position c0 + j > r, i.e. j > lane - (c0 - row0))
-            const int j_min = lane + 1 - (int)(c0 - row0);
-            if (nc < 64) h &= (1ull << nc) - 1ull;
-            if (j_min > 0) h = j_min >= 64 ? 0ull : h & ~((1ull << j_min) - 1ull);
-            if ((uint32_t)lane >= n_rows) h = 0ull;
-            while (__any(h != 0ull)) { // one hit per lane and round
-                const unsigned long long bal = __ballot(h != 0ull);
-                if (h) {
-                    const int j = __builtin_ctzll(h);
-                    h &= h - 1ull;
-                    hitq[nq + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] =
-                        make_uint2(r, c0 + (uint32_t)j);
+            for (uint32_t c0 = col0; c0 < col1; c0 += 64) {
+                // (a task of several tiles -- a sub-bucket beyond 1025 entries: the next 64 columns
+                // under way while these are walked)
+                const uint32_t cn_pos = c0 + 64u + (uint32_t)lane;
+                KeyT kn = pad_col<KeyT>();
+                if (c0 + 64u < col1 && cn_pos < end) kn = loop_key<CK>(sub[cn_pos]);
+                const uint32_t nc = (g.dbg & 2u) ? 0u : min(64u, end - c0);
+                uint32_t hlo = 0, hhi = 0; // bit j: this lane's row is within k of column j of the tile
+                hlo = columns32<CK, 0>(x, ky, a.k, lim2);
+                if (nc > 32) hhi = columns32<CK, 32>(x, ky, a.k, lim2);
+                unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
+                // the columns this lane's row may pair with: inside the tile, and behind the row
+                // (position c0 + j > r, i.e. j > lane - (c0 - row0))
+                const int j_min = lane + 1 - (int)(c0 - row0);
+                if (nc < 64) h &= (1ull << nc) - 1ull;
+                if (j_min > 0) h = j_min >= 64 ? 0ull : h & ~((1ull << j_min) - 1ull);
+                if ((uint32_t)lane >= n_rows) h = 0ull;
+                while (__any(h != 0ull)) { // one hit per lane and round
+                    const unsigned long long bal = __ballot(h != 0ull);
+                    if (h) {
+                        const int j = __builtin_ctzll(h);
+                        h &= h - 1ull;
+                        hitq[nq + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] =
+                            make_uint2(r, c0 + (uint32_t)j);
+                    }
+                    nq += (uint32_t)__builtin_popcountll(bal);
+                    if (nq >= DRAIN_AT) drain();
                 }
-                nq += (uint32_t)__builtin_popcountll(bal);
-                if (nq >= 64) drain();
+                ky = kn;
             }
-            ky = kn;
         }
+        if (!has1) break;
+        t = t1;
+        tw = tw1;
+        tw1 = tw2;
+        x = x1;
+        ky = ky1;
     }
     if (nq) drain();
     { // what the stage still holds goes to this block's own slot (seg_edge_append_kernel moves it)
@@ -602,17 +791,38 @@ hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *f
     return hipGetLastError();
 }
 
+// one-wave blocks of the pair kernel that fit a CU at once (the waves are persistent: a block that
+// starts after the others have left finds its work done, or -- dealt statically -- does it alone)
+int seg_pair_blocks_per_cu(bool key32, bool has_n, bool ckey)
+{
+    int nb = 0;
+    hipError_t e;
+    if (key32 && ckey)
+        e = has_n ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint32_t, true, true>, 64, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint32_t, false, true>, 64, 0);
+    else if (key32)
+        e = has_n ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint32_t, true, false>, 64, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint32_t, false, false>, 64, 0);
+    else
+        e = has_n ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint64_t, true, false>, 64, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, seg_pair_kernel<uint64_t, false, false>, 64, 0);
+    return e == hipSuccess && nb > 0 ? nb : 16;
+}
+
 hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
                             uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s)
 {
     if (g.n_chunks == 0 || n_blocks == 0) return hipSuccess;
     const bool has_n = a.nmask != nullptr;
-    if (key32) {
-        if (has_n) seg_pair_kernel<uint32_t, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
-        else seg_pair_kernel<uint32_t, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+    if (key32 && g.use_ckey) {
+        if (has_n) seg_pair_kernel<uint32_t, true, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        else seg_pair_kernel<uint32_t, false, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+    } else if (key32) {
+        if (has_n) seg_pair_kernel<uint32_t, true, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        else seg_pair_kernel<uint32_t, false, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
     } else {
-        if (has_n) seg_pair_kernel<uint64_t, true><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
-        else seg_pair_kernel<uint64_t, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        if (has_n) seg_pair_kernel<uint64_t, true, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+        else seg_pair_kernel<uint64_t, false, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
     }
     seg_edge_scan_kernel<<<1, 1024, 0, s>>>(g.priv_cnt, n_blocks, a.counters);
     seg_edge_move_kernel<<<n_blocks, 64, 0, s>>>(g, g.priv_cnt, n_blocks, a.edges,
