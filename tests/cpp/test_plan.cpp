@@ -47,6 +47,38 @@ static void check_plan(const std::vector<uint64_t> &off, int umi_len, int k, uin
     const bool key32 = umi_len <= 16;
     build_plan(off.data(), nb, small_max, use_bs, umi_len, fused_max, prune, cache_prefix, tables, min_run, seg_min, k,
                key32, pl);
+    { // the same plan through the table pre-pass (what the library does): copy, counters, tables
+        TablePass tp;
+        std::vector<uint64_t> copy(nb + 1, 0xDEADull);
+        scan_table(off.data(), nb, fused_max, copy.data(), tp);
+        CHECK(tp.bad_at == ~0ull && copy == off, "table pass: copy / monotone");
+        Plan p2;
+        build_plan(off.data(), nb, small_max, use_bs, umi_len, fused_max, prune, cache_prefix, tables, min_run, seg_min,
+                   k, key32, p2, &tp);
+        CHECK(p2.n_fused == pl.n_fused && p2.n_pairs == pl.n_pairs && p2.n_pairs_eval == pl.n_pairs_eval &&
+                  p2.max_bucket == pl.max_bucket,
+              "table pass: counters %" PRIu64 " %" PRIu64 " %" PRIu64 " %" PRIu64 " vs %" PRIu64 " %" PRIu64 " %" PRIu64 " %" PRIu64,
+              p2.n_fused, p2.n_pairs, p2.n_pairs_eval, p2.max_bucket, pl.n_fused, pl.n_pairs, pl.n_pairs_eval, pl.max_bucket);
+        CHECK(p2.ranges.size() == pl.ranges.size() && p2.segs.size() == pl.segs.size() &&
+                  p2.small_tasks.size() == pl.small_tasks.size() && p2.big_tasks.size() == pl.big_tasks.size() &&
+                  p2.bs_buckets.size() == pl.bs_buckets.size() && p2.seg_blocks.size() == pl.seg_blocks.size() &&
+                  p2.seg_task_cap == pl.seg_task_cap && p2.plane_words == pl.plane_words,
+              "table pass: tables");
+        for (size_t i = 0; i < pl.ranges.size(); i++)
+            CHECK(p2.ranges[i].start == pl.ranges[i].start && p2.ranges[i].end == pl.ranges[i].end &&
+                      p2.ranges[i].seg == pl.ranges[i].seg, "table pass: range %zu", i);
+        if (nb > 1) { // a step backwards is reported at its bucket
+            std::vector<uint64_t> broken = off;
+            const uint64_t at = nb / 2;
+            if (broken[at + 1] > 0) {
+                broken[at + 1] = broken[at] > 0 ? broken[at] - 1 : 0;
+                if (broken[at + 1] < broken[at]) {
+                    scan_table(broken.data(), nb, fused_max, nullptr, tp);
+                    CHECK(tp.bad_at == at, "table pass: step backwards at %" PRIu64 " reported at %" PRIu64, at, tp.bad_at);
+                }
+            }
+        }
+    }
     gen_bs_tasks(pl, umi_len, col_chunk, k, nullptr, key32);
     // per bucket: pairs covered by each family of tasks
     std::map<uint64_t, uint64_t> bucket_of_start; // start -> index

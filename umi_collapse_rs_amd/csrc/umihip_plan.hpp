@@ -222,10 +222,122 @@ inline void plan_segment(Plan &pl, uint64_t s, uint64_t e, int umi_len, int k, b
     pl.segs.push_back(sd);
 }
 
+// One pass over the bucket table of a call, before anything else looks at it: the copy for the
+// upload (pinned staging), the monotonicity check, and everything the plan needs of the buckets
+// the fused one-wave kernel takes -- for a batch of 10^5 small positions that is the whole plan, and
+// the host's walk over the table is what the step waits for (the kernel is enqueued first), so
+// the walk is a branch-free loop the compiler vectorises; a block of buckets that holds a larger
+// one (or a step backwards) is walked again the slow way, and those buckets' indices are all
+// build_plan visits.
+struct TablePass {
+    uint64_t n_fused = 0, n_pairs = 0, n_pairs_eval = 0, max_bucket = 0;
+    uint64_t bad_at = ~0ull; // first bucket whose end lies before its start
+    std::vector<uint64_t> large; // buckets of more than fused_max entries, ascending
+};
+struct TableBlockSums {
+    uint64_t fused, pairs, eval, mx, over;
+};
+// buckets [b0, b1) of the table, b1 - b0 <= 2048, fused_max <= 1024: sums fit 32 bits
+#define UMIHIP_TABLE_BLOCK_BODY                                                                         \
+    uint32_t fused = 0, pairs = 0, eval = 0, mx = 0, over = 0;                                          \
+    for (uint64_t b = b0; b < b1; b++) {                                                                \
+        const uint64_t e = bucket_off[b + 1];                                                           \
+        const uint64_t n = e - bucket_off[b]; /* (a step backwards wraps: "large") */                   \
+        if (copy) copy[b + 1] = e;                                                                      \
+        const uint32_t small = n <= fused_max ? ~0u : 0u;                                               \
+        const uint32_t m = (uint32_t)n & small;                                                         \
+        fused += m != 0;                                                                                \
+        pairs += m * (m - 1u) / 2u; /* (0 for m = 0: the product wraps to 0) */                         \
+        eval += m >= 2 ? m * m : 0u;                                                                    \
+        mx = m > mx ? m : mx;                                                                           \
+        over |= ~small;                                                                                 \
+    }                                                                                                   \
+    return TableBlockSums{fused, pairs, eval, mx, over};
+inline TableBlockSums table_block_generic(const uint64_t *__restrict bucket_off, uint64_t b0, uint64_t b1,
+                                          uint32_t fused_max, uint64_t *__restrict copy)
+{
+    UMIHIP_TABLE_BLOCK_BODY
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline TableBlockSums table_block_avx2(const uint64_t *__restrict bucket_off,
+                                                                        uint64_t b0, uint64_t b1, uint32_t fused_max,
+                                                                        uint64_t *__restrict copy)
+{
+    UMIHIP_TABLE_BLOCK_BODY
+}
+#endif
+#undef UMIHIP_TABLE_BLOCK_BODY
+
+inline void scan_table_reset(TablePass &tp)
+{
+    tp.n_fused = tp.n_pairs = tp.n_pairs_eval = tp.max_bucket = 0;
+    tp.bad_at = ~0ull;
+    tp.large.clear();
+}
+// buckets [b_begin, b_end) (copy[b_begin] is the caller's): the table may be walked in pieces, each
+// uploaded and handed to the fused kernel while the next is walked
+inline void scan_table_range(const uint64_t *__restrict bucket_off, uint64_t b_begin, uint64_t b_end,
+                             uint32_t fused_max, uint64_t *__restrict copy, TablePass &tp)
+{
+#if defined(__x86_64__)
+    const bool avx2 = __builtin_cpu_supports("avx2");
+#endif
+    constexpr uint64_t BLOCK = 2048;
+    for (uint64_t b0 = b_begin; b0 < b_end; b0 += BLOCK) {
+        const uint64_t b1 = std::min(b_end, b0 + BLOCK);
+        TableBlockSums t;
+        if (fused_max > 1024) { // (not the fused kernel's range: the 32-bit sums could wrap)
+            t = TableBlockSums{0, 0, 0, 0, 0};
+            for (uint64_t b = b0; b < b1; b++) {
+                const uint64_t e = bucket_off[b + 1], n = e - bucket_off[b];
+                if (copy) copy[b + 1] = e;
+                if (n <= fused_max) {
+                    t.fused += n != 0;
+                    t.pairs += n ? n * (n - 1) / 2 : 0;
+                    t.eval += n >= 2 ? n * n : 0;
+                    t.mx = std::max(t.mx, n);
+                } else {
+                    t.over = 1;
+                }
+            }
+        } else {
+#if defined(__x86_64__)
+            t = avx2 ? table_block_avx2(bucket_off, b0, b1, fused_max, copy)
+                     : table_block_generic(bucket_off, b0, b1, fused_max, copy);
+#else
+            t = table_block_generic(bucket_off, b0, b1, fused_max, copy);
+#endif
+        }
+        tp.n_fused += t.fused;
+        tp.n_pairs += t.pairs;
+        tp.n_pairs_eval += t.eval;
+        tp.max_bucket = std::max(tp.max_bucket, t.mx);
+        if (t.over)
+            for (uint64_t b = b0; b < b1; b++) {
+                if (bucket_off[b + 1] < bucket_off[b]) {
+                    if (tp.bad_at == ~0ull) tp.bad_at = b;
+                } else if (bucket_off[b + 1] - bucket_off[b] > fused_max) {
+                    tp.large.push_back(b);
+                }
+            }
+    }
+}
+
+inline void scan_table(const uint64_t *__restrict bucket_off, uint64_t n_buckets, uint32_t fused_max,
+                       uint64_t *__restrict copy, TablePass &tp)
+{
+    scan_table_reset(tp);
+    if (copy) copy[0] = bucket_off[0];
+    scan_table_range(bucket_off, 0, n_buckets, fused_max, copy, tp);
+}
+
 // seg_min: buckets of at least this many entries go through the segment index (0: none do)
+// pass (may be null): the table has been walked by scan_table with the same fused_max -- only its
+// large buckets are visited here, the others' share of the counters comes from it
 inline void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t small_max, bool use_bs,
                 int umi_len, uint32_t fused_max, bool narrow_only, bool cache_prefix, bool tables,
-                uint32_t tab_min_run, uint32_t seg_min, int k, bool key32, Plan &pl)
+                uint32_t tab_min_run, uint32_t seg_min, int k, bool key32, Plan &pl,
+                const TablePass *pass = nullptr)
 {
     pl.segs.clear();
     pl.seg_chunks.clear();
@@ -256,7 +368,15 @@ inline void build_plan(const uint64_t *bucket_off, uint64_t n_buckets, uint32_t 
     pl.plane_words = 0;
     pl.n_pairs = pl.n_pairs_eval = pl.max_bucket = pl.n_tasks_pruned = 0;
     const uint32_t np = 2 * (uint32_t)bs_padded_len(umi_len);
-    for (uint64_t b = 0; b < n_buckets; b++) {
+    if (pass) {
+        pl.n_fused = pass->n_fused;
+        pl.n_pairs = pass->n_pairs;
+        pl.n_pairs_eval = pass->n_pairs_eval;
+        pl.max_bucket = pass->max_bucket;
+    }
+    const uint64_t n_visit = pass ? pass->large.size() : n_buckets;
+    for (uint64_t vi = 0; vi < n_visit; vi++) {
+        const uint64_t b = pass ? pass->large[vi] : vi;
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
         const uint64_t n = e - s;
         pl.max_bucket = std::max(pl.max_bucket, n);
