@@ -132,6 +132,34 @@ int umi_abi_version(void);
 int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys,
                     uint64_t *nmask);
 
+/* ---- read staging on the device: the per-read part of
+ *      DeduplicateSAM::deduplicate_and_merge, src/deduplicate_sam.rs:148-176
+ *      (to_bitset per read, the per-position map UMI -> ReadFreq with freq += 1 and the kept read
+ *      chosen by Merge, src/merge/mod.rs:18-51), and the rank order of a position's UMIs
+ *      (src/algo/directional.rs:67-72), in the canonical determinisation: positions by first
+ *      appearance in the file, UMIs of a position by freq descending, ties by first appearance.
+ * in : per read, in file order: align_key (the caller's injective packing of the reference's
+ *      Alignment -- strand, unclipped position, reference id, deduplicate_sam.rs:141-145,507-514 --
+ *      into 64 bits, or any dense id; only its low align_key_bits bits are looked at),
+ *      umi_len ASCII bytes of UMI, score (avg qual or mapq, may be NULL).
+ *      merge: 0 = keep the first read of a UMI (merge "any"), 1 = the highest score, the first
+ *      on ties (merge/mod.rs:35,49).
+ * out: the batched path's input -- keys / nmask (may be NULL) / freq per unique (position, UMI)
+ *      in canonical order, rep = file index of the read that represents it, bucket_off
+ *      [*n_buckets + 1]; capacity n_reads (bucket_off: n_reads + 1), caller-owned.
+ * UMI_ERR_CHAR for a character outside ATCGN (the reference panics, utils/mod.rs:77-79).
+ * The _device form takes and leaves everything in device memory (one synchronisation inside for
+ * the two counts); the plain form copies host arrays in and out around it. */
+int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits,
+                           const uint8_t *d_umi_ascii, const int32_t *d_score, uint64_t n_reads,
+                           int umi_len, int merge, uint64_t *d_keys, uint64_t *d_nmask,
+                           int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
+                           uint64_t *n_entries, uint64_t *n_buckets, void *hip_stream);
+int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits,
+                    const uint8_t *umi_ascii, const int32_t *score, uint64_t n_reads, int umi_len,
+                    int merge, uint64_t *keys, uint64_t *nmask, int32_t *freq, uint64_t *rep,
+                    uint64_t *bucket_off, uint64_t *n_entries, uint64_t *n_buckets);
+
 /* ---- batched path: replaces the whole bucket loop
  *      src/deduplicate_sam.rs:207-233 (apply::<UcSAMRead,Naive> per bucket,
  *      counters :217-219) = Directional/Adjacency::apply

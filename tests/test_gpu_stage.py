@@ -1,0 +1,96 @@
+"""Read staging on the device (umi_stage_reads, SURVEY.md 8f N2's "second kernel") against the
+oracle's restatement of src/deduplicate_sam.rs:148-176 (orc_stage_reads): keys, N masks, freq,
+representative reads and the bucket table bit for bit, in the canonical order."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import umi_collapse_rs_amd as umi
+    c = umi.Context(0)
+    yield c
+    c.close()
+
+
+ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def make_reads(rng, n_reads, n_pos, L, n_mol, err=0.03, n_frac=0.0, sorted_file=True):
+    """Reads of a molecule model: positions, per position a few molecules, copies with errors."""
+    pos = rng.integers(0, n_pos, n_reads)
+    if sorted_file:
+        pos = np.sort(pos)
+    mol = rng.integers(0, n_mol, n_reads)
+    centres = rng.choice(ALPHA, (n_pos, n_mol, L))
+    umi = centres[pos, mol].copy()
+    flip = rng.random(umi.shape) < err
+    umi[flip] = rng.choice(ALPHA, int(flip.sum()))
+    if n_frac:
+        isn = rng.random(umi.shape) < n_frac
+        umi[isn] = ord("N")
+    score = rng.integers(0, 42, n_reads).astype(np.int32)
+    return pos, umi.reshape(-1), score
+
+
+def dense_ids(pos):
+    """Alignment-key ids numbered by first appearance (what orc_stage_reads is given)."""
+    _, first, inv = np.unique(pos, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first))
+    return order[inv].astype(np.uint32)
+
+
+def compare(got, want):
+    for f in ("bucket_off", "keys", "nmask", "freq", "rep"):
+        assert len(got[f]) == len(want[f]), (f, len(got[f]), len(want[f]))
+        assert (got[f] == want[f]).all(), (f, np.nonzero(got[f] != want[f])[0][:5])
+
+
+@pytest.mark.parametrize("n_reads,n_pos,L,n_mol,n_frac,merge,sorted_file", [
+    (20000, 300, 12, 8, 0.0, 1, True),      # BASELINE config 1 shape
+    (20000, 300, 12, 8, 0.01, 1, False),    # positions interleaved in the file, N bases
+    (50000, 1, 10, 3000, 0.0, 1, True),     # one deep position
+    (30000, 5000, 20, 2, 0.002, 0, False),  # 20-bp UMIs, merge "any", many tiny positions
+    (4000, 40, 21, 5, 0.0, 1, True),        # the longest one-word UMI
+    (100, 100, 5, 1, 0.0, 1, True),
+    (1, 1, 12, 1, 0.0, 1, True),
+])
+def test_staging_against_the_oracle(ctx, n_reads, n_pos, L, n_mol, n_frac, merge, sorted_file):
+    rng = np.random.default_rng(n_reads + 7 * L + merge)
+    pos, umi, score = make_reads(rng, n_reads, n_pos, L, n_mol, n_frac=n_frac, sorted_file=sorted_file)
+    want = orc.stage_reads(dense_ids(pos), umi, score, L, merge)
+    # the library takes any injective 64-bit key: the raw positions, scattered over all 64 bits
+    key = (pos.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    compare(ctx.stage_reads(key, umi, score, L, merge), want)
+    # ... or dense ids with the bit count that covers them
+    ids = dense_ids(pos).astype(np.uint64)
+    compare(ctx.stage_reads(ids, umi, score, L, merge, align_key_bits=max(1, int(ids.max()).bit_length())), want)
+    if merge:  # equal scores: the first read of a UMI stands for it (merge/mod.rs:35: >= keeps the earlier)
+        flat = np.full(n_reads, 30, np.int32)
+        compare(ctx.stage_reads(key, umi, flat, L, 1), orc.stage_reads(dense_ids(pos), umi, flat, L, 1))
+        compare(ctx.stage_reads(key, umi, None, L, 1), orc.stage_reads(dense_ids(pos), umi, None, L, 1))
+
+
+def test_staging_feeds_the_hot_path(ctx):
+    """stage -> dedup on the staged arrays == oracle staging -> oracle dedup: the survivors'
+    representative reads, in output order."""
+    rng = np.random.default_rng(99)
+    pos, umi, score = make_reads(rng, 60000, 200, 12, 30, err=0.02)
+    st = ctx.stage_reads(pos.astype(np.uint64), umi, score, 12, 1)
+    kept, _, _ = ctx.dedup_batch(st["keys"], None, st["freq"], st["bucket_off"], 12, k=1)
+    ost = orc.stage_reads(dense_ids(pos), umi, score, 12, 1)
+    okept, _, _ = orc.dedup_batch(ost["keys"], None, ost["freq"], ost["bucket_off"], 12, 1)
+    assert (st["rep"][kept.astype(bool)] == ost["rep"][okept.astype(bool)]).all()
+
+
+def test_staging_rejects_what_the_reference_panics_on(ctx):
+    import umi_collapse_rs_amd as umi
+    umis = np.frombuffer(b"ACGTACGTACGTACGTACGTacgt", dtype=np.uint8)  # lowercase: utils/mod.rs:77-79
+    with pytest.raises(umi.UmiHipError):
+        ctx.stage_reads(np.zeros(2, np.uint64), umis, None, 12)
+    st = ctx.stage_reads(np.zeros(0, np.uint64), np.zeros(0, np.uint8), None, 12)  # no reads at all
+    assert len(st["keys"]) == 0 and st["bucket_off"].tolist() == [0]

@@ -99,6 +99,36 @@ class Context:
                                      C.byref(st)))
         return kept, root, st.as_dict()
 
+    def stage_reads(self, align_key, umi_bytes, score, umi_len, merge=1, align_key_bits=64):
+        """Read staging on the device (host arrays in and out): reads in file order ->
+        dict(keys, nmask, freq, rep, bucket_off) in canonical order, the batched path's input
+        (src/deduplicate_sam.rs:148-176 + the rank order of src/algo/directional.rs:67-72)."""
+        align_key = np.ascontiguousarray(align_key, dtype=np.uint64)
+        umi_bytes = np.ascontiguousarray(umi_bytes, dtype=np.uint8)
+        sc = None if score is None else np.ascontiguousarray(score, dtype=np.int32)
+        n = len(align_key)
+        assert len(umi_bytes) == n * umi_len
+        m = max(1, n)
+        keys, nm, rep = (np.zeros(m, np.uint64) for _ in range(3))
+        freq = np.zeros(m, np.int32)
+        boff = np.zeros(m + 1, np.uint64)
+        ne, nb = C.c_uint64(0), C.c_uint64(0)
+        check(load().umi_stage_reads(self._h, ptr(align_key, C.c_uint64), align_key_bits,
+                                        ptr(umi_bytes, C.c_uint8), ptr(sc, C.c_int32), n, umi_len, merge,
+                                        ptr(keys, C.c_uint64), ptr(nm, C.c_uint64), ptr(freq, C.c_int32),
+                                        ptr(rep, C.c_uint64), ptr(boff, C.c_uint64), C.byref(ne), C.byref(nb)))
+        e, b = int(ne.value), int(nb.value)
+        return dict(keys=keys[:e], nmask=nm[:e], freq=freq[:e], rep=rep[:e], bucket_off=boff[:b + 1])
+
+    def stage_reads_device(self, d_align_key, d_umi, d_score, n_reads, umi_len, d_keys, d_nmask, d_freq,
+                           d_rep, d_bucket_off, merge=1, align_key_bits=64, stream=0):
+        """The same with everything in device memory (raw pointers); returns (n_entries, n_buckets)."""
+        ne, nb = C.c_uint64(0), C.c_uint64(0)
+        check(load().umi_stage_reads_device(self._h, d_align_key, align_key_bits, d_umi, d_score or None,
+                                               n_reads, umi_len, merge, d_keys, d_nmask or None, d_freq, d_rep,
+                                               d_bucket_off, C.byref(ne), C.byref(nb), stream or None))
+        return int(ne.value), int(nb.value)
+
     def dedup_batch_device(self, d_keys, d_nmask, d_freq, bucket_off, umi_len, d_kept, d_root=0,
                            k=1, percentage=0.5, algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0,
                            stream=0):

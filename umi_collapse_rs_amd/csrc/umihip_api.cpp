@@ -167,6 +167,8 @@ struct umi_ctx {
     TablePass table_pass;
     // staging for the host-buffer entry point
     DevBuf in_keys, in_nmask, in_freq, out_kept, out_root;
+    // read staging (umi_stage_reads*): workspace; device copies of the host-buffer form
+    DevBuf stage_ws, st_align, st_umi, st_score, st_keys, st_nmask, st_freq, st_rep, st_boff;
     uint64_t *h_boff = nullptr;               // pinned staging of the bucket table
     size_t h_boff_cap = 0;
     PinnedBuf h_tasks;                        // pinned staging of the bit-sliced tile-task lists
@@ -1473,7 +1475,9 @@ void umi_ctx_destroy(umi_ctx *ctx)
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
                       &ctx->edge_dist, &ctx->counters,
                       &ctx->boff,    &ctx->status,   &ctx->blocked,  &ctx->in_keys,
-                      &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root};
+                      &ctx->in_nmask, &ctx->in_freq, &ctx->out_kept, &ctx->out_root,
+                      &ctx->stage_ws, &ctx->st_align, &ctx->st_umi, &ctx->st_score, &ctx->st_keys, &ctx->st_nmask,
+                      &ctx->st_freq, &ctx->st_rep, &ctx->st_boff};
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
     ctx->h_tasks.release();
@@ -1646,6 +1650,72 @@ int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_
     if (n && (!d_kept || !d_bits)) return fail(UMI_ERR_ARG, "kept/bits is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(launch_pack_mask(d_kept, n, d_bits, (hipStream_t)hip_stream));
+    return UMI_OK;
+}
+
+int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits, const uint8_t *d_umi_ascii,
+                           const int32_t *d_score, uint64_t n_reads, int umi_len, int merge, uint64_t *d_keys,
+                           uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
+                           uint64_t *n_entries, uint64_t *n_buckets, void *hip_stream)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) ctx = ctx->subs[0]; // (staging runs on the first device of a multi-device context)
+    if (!n_entries || !n_buckets || !d_bucket_off) return fail(UMI_ERR_ARG, "n_entries / n_buckets / d_bucket_off is NULL");
+    if (n_reads && (!d_align_key || !d_umi_ascii || !d_keys || !d_freq || !d_rep))
+        return fail(UMI_ERR_ARG, "a required device pointer is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (align_key_bits < 1 || align_key_bits > 64) return fail(UMI_ERR_ARG, "align_key_bits must be in 1..64");
+    if (merge != 0 && merge != 1) return fail(UMI_ERR_ARG, "merge must be 0 (any) or 1 (highest score, first on ties)");
+    if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads)))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    const int r = stage_reads_on_device(ctx->stage_ws.p, d_align_key, align_key_bits, d_umi_ascii, d_score,
+                                        (uint32_t)n_reads, umi_len, merge, d_keys, d_nmask, d_freq, d_rep, d_bucket_off,
+                                        n_entries, n_buckets, ctx->h_counters, s);
+    if (r == 1) return fail(UMI_ERR_CHAR, "Unknown character in UMI sequence");
+    if (r < 0) return fail(UMI_ERR_HIP, "staging: %s", hipGetErrorString((hipError_t)(-r)));
+    return UMI_OK;
+}
+
+int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits, const uint8_t *umi_ascii,
+                    const int32_t *score, uint64_t n_reads, int umi_len, int merge, uint64_t *keys, uint64_t *nmask,
+                    int32_t *freq, uint64_t *rep, uint64_t *bucket_off, uint64_t *n_entries, uint64_t *n_buckets)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) ctx = ctx->subs[0];
+    if (!n_entries || !n_buckets || !bucket_off) return fail(UMI_ERR_ARG, "n_entries / n_buckets / bucket_off is NULL");
+    if (n_reads && (!align_key || !umi_ascii || !keys || !freq || !rep)) return fail(UMI_ERR_ARG, "a required pointer is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    const size_t n = (size_t)n_reads, m = std::max<size_t>(n, 1);
+    if ((rc = ctx->st_align.reserve(m * 8)) || (rc = ctx->st_umi.reserve(m * (size_t)umi_len)) ||
+        (rc = ctx->st_score.reserve(m * 4)) || (rc = ctx->st_keys.reserve(m * 8)) || (rc = ctx->st_nmask.reserve(m * 8)) ||
+        (rc = ctx->st_freq.reserve(m * 4)) || (rc = ctx->st_rep.reserve(m * 8)) || (rc = ctx->st_boff.reserve((m + 1) * 8)))
+        return rc;
+    hipStream_t s = ctx->own_stream;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(ctx->st_align.p, align_key, n * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ctx->st_umi.p, umi_ascii, n * (size_t)umi_len, hipMemcpyHostToDevice, s));
+        if (score) HIP_TRY(hipMemcpyAsync(ctx->st_score.p, score, n * 4, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = umi_stage_reads_device(ctx, ctx->st_align.as<uint64_t>(), align_key_bits, ctx->st_umi.as<uint8_t>(),
+                                     score ? ctx->st_score.as<int32_t>() : nullptr, n_reads, umi_len, merge,
+                                     ctx->st_keys.as<uint64_t>(), ctx->st_nmask.as<uint64_t>(), ctx->st_freq.as<int32_t>(),
+                                     ctx->st_rep.as<uint64_t>(), ctx->st_boff.as<uint64_t>(), n_entries, n_buckets, s)))
+        return rc;
+    const size_t e = (size_t)*n_entries, b = (size_t)*n_buckets;
+    if (e) {
+        HIP_TRY(hipMemcpyAsync(keys, ctx->st_keys.p, e * 8, hipMemcpyDeviceToHost, s));
+        if (nmask) HIP_TRY(hipMemcpyAsync(nmask, ctx->st_nmask.p, e * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(freq, ctx->st_freq.p, e * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rep, ctx->st_rep.p, e * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(bucket_off, ctx->st_boff.p, (b + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return UMI_OK;
 }
 

@@ -252,6 +252,17 @@ int seg_pair_blocks_per_cu(bool key32, bool has_n, bool ckey);
 hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
                             uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s);
 
+// ---- read staging on the device (umihip_stage.hip) ----
+size_t stage_workspace_bytes(uint32_t n_reads);
+// reads (alignment key, UMI text, score) -> entries in canonical order + bucket table, all device
+// memory; h_pinned4: four pinned 64-bit words for the counts the host needs on the way.
+// 0 ok; 1 a character outside ATCGN; negative: -(hipError_t)
+int stage_reads_on_device(void *workspace, const uint64_t *d_align, int align_bits, const uint8_t *d_umi,
+                          const int32_t *d_score, uint32_t n, int umi_len, int merge, uint64_t *d_keys,
+                          uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
+                          uint64_t *n_entries_out, uint64_t *n_buckets_out, unsigned long long *h_pinned4,
+                          hipStream_t s);
+
 // ---- directional collapse by union-find (umihip_collapse.hip) ----
 // comp[] (= label[], identity on entry) becomes the smallest index of each entry's set under the
 // symmetric pairs; lab[] is initialised to the identity
