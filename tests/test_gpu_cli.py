@@ -121,3 +121,25 @@ def test_tag_mode_writes_every_read_with_its_cluster(tmp_path, extra, kw):
     assert orecs == exp
     assert "Number of groups of reads: %d" % groups in log
     assert len(orecs) > groups or kw.get("algo") == "adj"
+
+
+@pytest.mark.parametrize("extra,kw", [
+    (["--merge", "avgqual"], dict(merge="avgqual")),
+    (["--merge", "any", "-k", "2"], dict(merge="any", k=2)),
+    (["--algo", "adj", "--keep-unmapped"], dict(algo="adj", merge="mapqual", keep_unmapped=True)),
+])
+def test_staging_on_the_gpu_and_on_the_host_write_the_same_file(tmp_path, extra, kw):
+    """--stage gpu (umi_stage_reads: sorts + segmented merge on the device) and --stage host (the
+    threaded hash-map staging) against the restatement, clipped reads, both strands, several
+    references and N bases included; the two output files are the same bytes."""
+    header, recs = bamio.synthetic_bam(11, 400, 50, umi_len=12, err=0.03)
+    outs = {}
+    for where in ("gpu", "host"):
+        d = tmp_path / where
+        d.mkdir()
+        oh, orecs, log = run_cli(d, header, recs, extra + ["--stage", where])
+        assert "staging (%s)" % where in log
+        outs[where] = open(str(d / "out.bam"), "rb").read()
+        exp, _ = bamio.expected_output(recs, **kw)
+        assert oh == header and orecs == exp
+    assert outs["gpu"] == outs["host"]

@@ -43,6 +43,9 @@ struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
     std::string dump_staging; // write the staged hot-path input here and stop before the GPU
     bool passthrough = false; // write every mapped record back (codec round trip), no dedup
     std::vector<int> devices{0}; // --device <ID> or --devices <ID,ID,...>
+    std::string stage = "auto";  // --stage gpu|host|auto: where the reads are merged per (position, UMI) and
+                                 // put in rank order (auto: on the GPU unless --paired or --tag need the
+                                 // host's per-read bookkeeping)
 };
 
 [[noreturn]] void die(const std::string &msg)
@@ -72,6 +75,7 @@ void usage()
               "      --tag                Write every read tagged with its cluster (MI, cs, su) instead of\n"
               "                           removing duplicates\n"
               "      --two-pass           accepted and rejected (see header)\n"
+              "      --stage <WHERE>      gpu, host or auto: where reads are merged per (position, UMI) [default: auto]\n"
               "      --device <ID>        GPU to use [default: 0]\n"
               "      --devices <ID,..>    several GPUs of the node: alignment positions are sharded over them");
 }
@@ -104,6 +108,7 @@ Cli parse(int argc, char **argv)
         else if (a == "--tag") c.track_clusters = true;
         else if (a == "--dump-staging") c.dump_staging = need(i);
         else if (a == "--passthrough") c.passthrough = true;
+        else if (a == "--stage") c.stage = need(i);
         else if (a == "--device") c.devices.assign(1, std::atoi(need(i)));
         else if (a == "--devices") { // the GPUs of the node the position buckets are sharded over
             c.devices.clear();
@@ -245,6 +250,7 @@ int main(int argc, char **argv)
             uint8_t state; // 0 staged, 1 unmapped, 2 error, 3 second mate (not counted),
                            // 4 mate unmapped, 5 filtered (--remove-unpaired / --remove-chimeric)
             uint8_t unpaired, chimeric;
+            uint32_t umi_at; // offset of the UMI in the read name
         };
         std::vector<ReadInfo> info(n_rec);
         std::vector<std::string> errors(T);
@@ -277,6 +283,7 @@ int main(int argc, char **argv)
                     continue;
                 }
                 ii.score = merge == 2 ? (int32_t)r.mapq() : r.avg_qual();
+                ii.umi_at = (uint32_t)at;
             }
         });
         for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
@@ -297,6 +304,73 @@ int main(int argc, char **argv)
             }
         }
 
+        // ---- staging: reads -> unique (position, UMI) entries in canonical order (:148-176 and the
+        // rank order of directional.rs:67-72).  On the GPU (umi_stage_reads: sorts and a segmented
+        // merge) where the alignment key packs into 64 bits and nothing needs the per-read
+        // bookkeeping of the host version below; both give the same arrays.
+        size_t n = 0, nb = 0, max_umi = 0;
+        bool any_n = false;
+        std::vector<uint64_t> keys, nmask, off;
+        std::vector<int32_t> freq;
+        std::vector<uint32_t> rep;
+        std::vector<std::vector<uint32_t>> global_of;
+        std::vector<uint32_t> entry_of;
+        KeyHash hasher;
+        umi_ctx *ctx = nullptr;
+        double t_init = 0.0;
+        auto need_ctx = [&]() {
+            if (ctx) return;
+            const double t0 = now_s();
+            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) die(umi_last_error());
+            t_init += now_s() - t0;
+        };
+        if (args.stage != "auto" && args.stage != "gpu" && args.stage != "host") die("--stage wants gpu, host or auto");
+        bool gpu_stage = args.stage != "host" && !args.passthrough && !args.paired && !args.track_clusters &&
+                         args.dump_staging.empty() && umi_length >= 1;
+        if (args.stage == "gpu" && !gpu_stage) die("--stage gpu does not go with --paired, --tag or --dump-staging");
+        if (gpu_stage) {
+            std::vector<uint32_t> staged;
+            staged.reserve(n_rec);
+            for (uint32_t ri = 0; ri < n_rec; ri++)
+                if (info[ri].state == 0) staged.push_back(ri);
+            const size_t ns = staged.size();
+            std::vector<uint64_t> akey(ns), rep64(ns);
+            std::vector<uint8_t> umis(ns * umi_length);
+            std::vector<int32_t> sc(ns);
+            std::vector<uint8_t> fits(T, 1);
+            const size_t per = (ns + T - 1) / T;
+            umi::bgzf::parallel_for(T, T, [&](size_t t) {
+                for (size_t j = t * per; j < std::min(ns, (t + 1) * per); j++) {
+                    const uint32_t ri = staged[j];
+                    const ReadInfo &ii = info[ri];
+                    // Alignment{strand, coord, ref} in 64 bits: ref id (31) | strand (1) | coordinate (32)
+                    const int64_t c = (int64_t)ii.coord;
+                    if (c < INT32_MIN || c > INT32_MAX) fits[t] = 0;
+                    akey[j] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c;
+                    std::memcpy(&umis[j * umi_length], in.records[ri].qname() + ii.umi_at, umi_length);
+                    sc[j] = ii.score;
+                }
+            });
+            for (uint8_t f : fits) gpu_stage = gpu_stage && f;
+            if (gpu_stage) {
+                need_ctx();
+                keys.assign(ns, 0); nmask.assign(ns, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
+                uint64_t ne = 0, nbk = 0;
+                if (umi_stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, merge != 0 ? 1 : 0,
+                                    keys.data(), nmask.data(), freq.data(), rep64.data(), off.data(), &ne, &nbk) != UMI_OK)
+                    die(umi_last_error());
+                n = (size_t)ne;
+                nb = (size_t)nbk;
+                keys.resize(n); nmask.resize(n); freq.resize(n); off.resize(nb + 1);
+                rep.resize(n);
+                for (size_t i = 0; i < n; i++) {
+                    rep[i] = staged[rep64[i]];
+                    any_n |= nmask[i] != 0;
+                }
+                for (size_t b = 0; b < nb; b++) max_umi = std::max<size_t>(max_umi, off[b + 1] - off[b]);
+            }
+        }
+        if (!gpu_stage) {
         struct Shard {
             std::unordered_map<AlignKey, uint32_t, KeyHash> bucket_of; // Align -> local bucket
             std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // key -> local entry
@@ -305,8 +379,7 @@ int main(int argc, char **argv)
             std::vector<Entry> entries;
         };
         std::vector<Shard> shards(args.passthrough ? 0 : T);
-        std::vector<uint32_t> entry_of(args.track_clusters ? n_rec : 0); // read -> entry of its shard (--tag)
-        KeyHash hasher;
+        entry_of.assign(args.track_clusters ? n_rec : 0, 0); // read -> entry of its shard (--tag)
         umi::bgzf::parallel_for(shards.size(), T, [&](size_t t) {
             Shard &sh = shards[t];
             for (uint32_t ri = 0; ri < n_rec; ri++) {
@@ -340,27 +413,23 @@ int main(int argc, char **argv)
                 }
             }
         });
-        const double t_stage0 = now_s();
-        std::fprintf(stderr, "UMI collapsing reading finished in %.3f seconds\n", t_stage0 - t_start); // :178-183
 
         // buckets in order of first appearance; inside a bucket the stable freq-descending order
         // of directional.rs:67-72 (creation order of a bucket's entries = first appearance)
         struct BucketRef { uint32_t first, shard, local; };
         std::vector<BucketRef> order;
-        size_t n = 0;
         for (uint32_t t = 0; t < shards.size(); t++) {
             n += shards[t].entries.size();
             for (uint32_t b = 0; b < shards[t].bucket_entries.size(); b++)
                 order.push_back({shards[t].bucket_first[b], t, b});
         }
         std::sort(order.begin(), order.end(), [](const BucketRef &x, const BucketRef &y) { return x.first < y.first; });
-        const size_t nb = order.size();
-        std::vector<uint64_t> keys(n), nmask(n), off(nb + 1, 0);
-        std::vector<int32_t> freq(n);
-        std::vector<uint32_t> rep(n);
-        bool any_n = false;
-        size_t w = 0, max_umi = 0;
-        std::vector<std::vector<uint32_t>> global_of(args.track_clusters ? shards.size() : 0); // (shard, entry) -> index
+        nb = order.size();
+        keys.assign(n, 0); nmask.assign(n, 0); off.assign(nb + 1, 0);
+        freq.assign(n, 0);
+        rep.assign(n, 0);
+        size_t w = 0;
+        global_of.assign(args.track_clusters ? shards.size() : 0, {}); // (shard, entry) -> index
         for (size_t t = 0; t < global_of.size(); t++) global_of[t].resize(shards[t].entries.size());
         for (size_t b = 0; b < nb; b++) {
             Shard &sh = shards[order[b].shard];
@@ -376,6 +445,9 @@ int main(int argc, char **argv)
             off[b + 1] = w;
             max_umi = std::max(max_umi, v.size());
         }
+        }
+        const double t_stage0 = now_s();
+        std::fprintf(stderr, "UMI collapsing reading finished in %.3f seconds\n", t_stage0 - t_start); // :178-183
         if (!args.dump_staging.empty()) { // test hook: staged hot-path input, no GPU touched
             FILE *f = std::fopen(args.dump_staging.c_str(), "wb");
             if (!f) die("cannot open " + args.dump_staging);
@@ -395,8 +467,7 @@ int main(int argc, char **argv)
         std::memset(&st, 0, sizeof(st));
         double t_gpu0 = now_s(), t_gpu1 = t_gpu0;
         if (!args.passthrough && n) {
-            umi_ctx *ctx = nullptr;
-            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) die(umi_last_error());
+            need_ctx();
             // The reference accepts every --data value and always runs Naive
             // (deduplicate_sam.rs:210-213), so the result is the same for all of them.  Here
             // "naive" is the plain all-pairs tile walk; any other value (the default is
@@ -408,8 +479,8 @@ int main(int argc, char **argv)
                                 kept.data(), args.track_clusters ? root.data() : nullptr, &st) != UMI_OK)
                 die(umi_last_error());
             t_gpu1 = now_s();
-            umi_ctx_destroy(ctx);
         }
+        if (ctx) umi_ctx_destroy(ctx);
         // --tag: cluster id / size per entry from the root of every entry.  Survivors in index
         // order are the roots in the order ClusterTracker::track sees them (bucket by bucket,
         // rank order inside), so offset + idx (cluster_tracker.rs:88-100, deduplicate_sam.rs:215)
@@ -523,8 +594,9 @@ int main(int argc, char **argv)
         std::fprintf(stderr, args.track_clusters ? "Number of groups of reads: %llu\n" : "Number of reads after deduplicating: %llu\n",
                      (unsigned long long)st.n_kept); // :259-266
         std::fprintf(stderr,
-                     "phases: read+inflate %.3f s, staging %.3f s, hot path (H2D+GPU+D2H) %.3f s [%llu pairs], write %.3f s\n",
-                     t_read - t_start, t_stage0 - t_read, t_gpu1 - t_gpu0, (unsigned long long)st.n_pairs, t_end - t_gpu1);
+                     "phases: read+inflate %.3f s, staging (%s) %.3f s, gpu init %.3f s, hot path (H2D+GPU+D2H) %.3f s [%llu pairs], write %.3f s\n",
+                     t_read - t_start, gpu_stage ? "gpu" : "host", t_stage0 - t_read - (gpu_stage ? t_init : 0.0), t_init,
+                     t_gpu1 - t_gpu0, (unsigned long long)st.n_pairs, t_end - t_gpu1);
         std::fprintf(stderr, "UMI collapsing finished in %.3f seconds\n", t_end - t_start); // main.rs:97-102
     } catch (const std::exception &e) {
         die(e.what());
