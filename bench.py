@@ -338,6 +338,37 @@ def main():
         host_ms = (time.perf_counter() - t1) * 1e3
         assert int(hk.sum()) == kept_n
 
+    # read staging on the device (N2): the same 1,000,000 reads as UMI text + alignment key, resident
+    # in HBM, through umi_stage_reads_device; its output must be the arrays the timed steps ran on
+    staging = None
+    if rank == 0 and world == 1 and extras and cfg == "2":
+        b2 = synth.uniform_reads(2, args.reads, args.umi_len)
+        d_umi = torch.from_numpy(synth.BASES[b2].reshape(-1).copy()).to(dev)
+        d_akey = torch.zeros(args.reads, dtype=torch.int64, device=dev)
+        o_keys = torch.zeros(args.reads, dtype=torch.int64, device=dev)
+        o_freq = torch.zeros(args.reads, dtype=torch.int32, device=dev)
+        o_rep = torch.zeros(args.reads, dtype=torch.int64, device=dev)
+        o_off = torch.zeros(args.reads + 1, dtype=torch.int64, device=dev)
+
+        def stage_once():
+            return ctx.stage_reads_device(d_akey.data_ptr(), d_umi.data_ptr(), 0, args.reads, args.umi_len,
+                                          o_keys.data_ptr(), 0, o_freq.data_ptr(), o_rep.data_ptr(),
+                                          o_off.data_ptr(), merge=0, align_key_bits=1, stream=stream)
+        ne, nbk = stage_once()
+        assert ne == n and nbk == 1 and bool((o_keys[:n] == d_keys).all().item()) and bool((o_freq[:n] == d_freq).all().item())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_st = 10
+        for _ in range(n_st):
+            stage_once()
+        torch.cuda.synchronize()
+        ms_stage = (time.perf_counter() - t1) / n_st * 1e3
+        staging = {"ms_per_call": ms_stage, "reads_per_s": args.reads / (ms_stage * 1e-3),
+                   "reads_per_s_with_hot_path": args.reads / ((ms_stage + dt / args.steps * 1e3) * 1e-3),
+                   "note": "umi_stage_reads_device on the same reads (12-byte UMI text + alignment key per read, "
+                           "resident in HBM): encode, sort by (position, UMI, file index), merge equal UMIs, rank "
+                           "order; output equal to the arrays of the timed steps (checked)"}
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         mean = lambda f: float(np.mean([s[f] for s in stats]))
@@ -404,6 +435,7 @@ def main():
             "sustained": sustained,
             "sustained_ms_per_step": None if sustained is None else sustained["ms_per_step"],
             "reads_per_s": reads_total * args.steps / dt,
+            "staging_device": staging,
             "host_buffer_path": None if host_ms is None else {
                 "ms_per_call": host_ms, "pairs_per_s": w_local / (host_ms * 1e-3),
                 "note": "umi_dedup_batch with pageable host arrays: PCIe copies included"},

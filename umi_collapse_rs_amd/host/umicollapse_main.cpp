@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -51,7 +52,8 @@ struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
 [[noreturn]] void die(const std::string &msg)
 { // the reference panics (panic = "abort")
     std::fprintf(stderr, "umicollapse: %s\n", msg.c_str());
-    std::exit(101);
+    std::fflush(stderr);
+    std::_Exit(101); // (no static destructors: the GPU's start-up thread may still be running)
 }
 
 void usage()
@@ -203,6 +205,31 @@ int main(int argc, char **argv)
     else if (args.merge == "mapqual") merge = 2;
     else die("Invalid algorithm combination: " + args.algo + " , " + args.merge + " and " + args.data);
 
+    // The GPU is woken while the file is read: context creation and the first launch of the
+    // library's kernels (their code objects are loaded then) take ~0.1 s of a process that lives
+    // half a second, none of it on the device.  A tiny staging call and a tiny batch go through;
+    // whoever needs the context first waits for this thread.
+    std::future<umi_ctx *> warm;
+    std::string warm_error;
+    if (!args.passthrough && args.dump_staging.empty())
+        warm = std::async(std::launch::async, [&]() -> umi_ctx * {
+            umi_ctx *c = nullptr;
+            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &c) != UMI_OK) {
+                warm_error = umi_last_error();
+                return nullptr;
+            }
+            const uint64_t akey[2] = {0, 0};
+            const uint8_t umis[8] = {'A', 'C', 'G', 'T', 'A', 'C', 'G', 'A'};
+            uint64_t k[2], nm[2], rp[2], off[3], ne = 0, nbk = 0;
+            int32_t fr[2];
+            uint8_t kept[2];
+            umi_stats wst;
+            if (umi_stage_reads(c, akey, 1, umis, nullptr, 2, 4, 0, k, nm, fr, rp, off, &ne, &nbk) != UMI_OK ||
+                umi_dedup_batch(c, k, nullptr, fr, off, nbk, 4, 1, 0.5f, UMI_ALGO_DIRECTIONAL, 0, kept, nullptr, &wst) != UMI_OK)
+                warm_error = umi_last_error(); // (reported when the real call fails the same way)
+            return c;
+        });
+
     try {
         // ---- read: BGZF inflate (threaded) + BAM parse
         umi::bam::File in;
@@ -318,10 +345,15 @@ int main(int argc, char **argv)
         KeyHash hasher;
         umi_ctx *ctx = nullptr;
         double t_init = 0.0;
-        auto need_ctx = [&]() {
+        auto need_ctx = [&]() { // (t_init: what of the GPU's start-up was left to wait for)
             if (ctx) return;
             const double t0 = now_s();
-            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) die(umi_last_error());
+            if (warm.valid()) {
+                ctx = warm.get();
+                if (!ctx) die(warm_error);
+            } else if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) {
+                die(umi_last_error());
+            }
             t_init += now_s() - t0;
         };
         if (args.stage != "auto" && args.stage != "gpu" && args.stage != "host") die("--stage wants gpu, host or auto");
@@ -480,6 +512,7 @@ int main(int argc, char **argv)
                 die(umi_last_error());
             t_gpu1 = now_s();
         }
+        if (!ctx && warm.valid()) ctx = warm.get(); // (nothing to do for the GPU: still to be put away)
         if (ctx) umi_ctx_destroy(ctx);
         // --tag: cluster id / size per entry from the root of every entry.  Survivors in index
         // order are the roots in the order ClusterTracker::track sees them (bucket by bucket,
