@@ -245,6 +245,7 @@ def main():
     d_freq = torch.from_numpy(st["freq"]).to(dev)
     d_kept = torch.zeros(n, dtype=torch.uint8, device=dev)
     boff = st["bucket_off"]
+    d_boff = torch.from_numpy(np.ascontiguousarray(boff).view(np.int64)).to(dev)  # the table is an input too
     max_n = max(sizes)
     # the kept mask travels as bits: ceil(n / 8) bytes per rank, padded to the largest slice
     gather_in = torch.zeros((max_n + 7) // 8, dtype=torch.uint8, device=dev)
@@ -270,7 +271,7 @@ def main():
             return s
         s = c.dedup_batch_device(d_keys.data_ptr(), 0, d_freq.data_ptr(), boff, args.umi_len,
                                  d_kept.data_ptr(), 0, k=args.k, percentage=args.p,
-                                 stream=stream)
+                                 stream=stream, d_bucket_off=d_boff.data_ptr())
         if world > 1:  # all-gatherv of the kept mask: packed to bits on the device, padded all_gather
             c.pack_mask_device(d_kept.data_ptr(), n, gather_in.data_ptr(), stream=stream)  # over RCCL/xGMI
             dist.all_gather_into_tensor(gather_out, gather_in)

@@ -191,6 +191,17 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                            uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
                            int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
                            void *hip_stream, umi_stats *stats);
+/* The same with the bucket table resident on the device as well (d_bucket_off: a device copy of
+ * bucket_off, or NULL for the call above): nothing of the table is staged or uploaded inside the
+ * call -- for a batch of 10^5 small positions that copy is what the first kernel waits for.  The
+ * host copy is still the one that is validated and planned from; a device table that differs from
+ * it is the caller's error (entries it would lead outside the arrays are skipped and reported as
+ * UMI_ERR_ORDER). */
+int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                                 const int32_t *d_freq, const uint64_t *bucket_off,
+                                 const uint64_t *d_bucket_off, uint64_t n_buckets, int umi_len, int k,
+                                 float percentage, int algo, int32_t adj_max_freq, uint8_t *d_kept,
+                                 uint32_t *d_root, void *hip_stream, umi_stats *stats);
 
 /* The kept mask as one bit per entry (bit i % 8 of byte i / 8; ceil(n / 8) bytes at d_bits), packed
  * on the device and enqueued on hip_stream: what a one-process-per-GPU host all-gathers over RCCL

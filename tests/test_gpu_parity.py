@@ -474,6 +474,32 @@ def test_device_pointer_entry_point(ctx):
     assert (t_kept.cpu().numpy() == okept).all()
     assert (t_root.cpu().numpy().view(np.uint32) == oroot).all()
     assert st["n_kept"] == int(okept.sum())
+    # the bucket table resident on the device as well (umi_dedup_batch_device_table): same result,
+    # small buckets (fused kernel) and one beyond its reach (prep / rise check read the table too)
+    import umi_collapse_rs_amd as umi
+    keys2, nm2, fr2, off2 = make_batch(rng, 3000, 12, 40, err=0.05)
+    kb, nb_, fb, ob = make_batch(rng, 1, 12, 700, err=0.05, exact=True)
+    keys2 = np.concatenate([keys2, kb]); nm2 = np.concatenate([nm2, nb_]); fr2 = np.concatenate([fr2, fb])
+    off2 = np.concatenate([off2, off2[-1] + ob[1:]]).astype(np.uint64)
+    t_keys = torch.from_numpy(keys2.view(np.int64)).to(dev)
+    t_fr = torch.from_numpy(fr2).to(dev)
+    t_off = torch.from_numpy(off2.view(np.int64)).to(dev)
+    t_kept = torch.zeros(len(keys2), dtype=torch.uint8, device=dev)
+    t_root = torch.zeros(len(keys2), dtype=torch.int32, device=dev)
+    okept, oroot, _ = orc.dedup_batch(keys2, nm2, fr2, off2, 12, 1)
+    for table in (t_off.data_ptr(), 0):
+        t_kept.zero_()
+        st = ctx.dedup_batch_device(t_keys.data_ptr(), 0, t_fr.data_ptr(), off2, 12, t_kept.data_ptr(),
+                                    t_root.data_ptr(), k=1, stream=stream, d_bucket_off=table)
+        torch.cuda.synchronize()
+        assert (t_kept.cpu().numpy() == okept).all() and st["n_kept"] == int(okept.sum())
+        assert (t_root.cpu().numpy().view(np.uint32) == oroot).all()
+    # a device table that is not the host's: entries that would lead outside the arrays are refused
+    bad = torch.from_numpy((off2 + np.uint64(len(keys2))).view(np.int64)).to(dev)
+    with pytest.raises(umi.UmiHipError):
+        ctx.dedup_batch_device(t_keys.data_ptr(), 0, t_fr.data_ptr(), off2, 12, t_kept.data_ptr(),
+                               t_root.data_ptr(), k=1, stream=stream, d_bucket_off=bad.data_ptr())
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("L,k,n_raw,n_frac", [

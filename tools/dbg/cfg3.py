@@ -12,14 +12,15 @@ st = synth.config3(seed=int(cfg), n_reads=reads, n_positions=reads // 100, umi_l
 dev = torch.device("cuda", 0)
 dk = torch.from_numpy(st["keys"].view(np.int64)).to(dev); df = torch.from_numpy(st["freq"]).to(dev)
 n = len(st["keys"]); kept = torch.zeros(n, dtype=torch.uint8, device=dev)
+db = torch.from_numpy(np.ascontiguousarray(st["bucket_off"]).view(np.int64)).to(dev)
 ctx = umi.Context(0, profile=True)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(5):
-    ctx.dedup_batch_device(dk.data_ptr(), 0, df.data_ptr(), st["bucket_off"], L, kept.data_ptr(), 0, k=k, stream=s)
+    ctx.dedup_batch_device(dk.data_ptr(), 0, df.data_ptr(), st["bucket_off"], L, kept.data_ptr(), 0, k=k, stream=s, d_bucket_off=(db.data_ptr() if len(sys.argv) > 2 else 0))
 ts = []; ev = []
 for _ in range(20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    r = ctx.dedup_batch_device(dk.data_ptr(), 0, df.data_ptr(), st["bucket_off"], L, kept.data_ptr(), 0, k=k, stream=s)
+    r = ctx.dedup_batch_device(dk.data_ptr(), 0, df.data_ptr(), st["bucket_off"], L, kept.data_ptr(), 0, k=k, stream=s, d_bucket_off=(db.data_ptr() if len(sys.argv) > 2 else 0))
     ts.append(time.perf_counter() - t0); ev.append((r["ms_prep"], r["ms_pairs"], r["ms_collapse"], r["ms_finalize"], r["ms_total"]))
 print("config", cfg, "entries", n, "buckets", len(st["bucket_off"]) - 1)
 print("wall ms/call: median %.4f min %.4f" % (np.median(ts) * 1e3, min(ts) * 1e3))

@@ -131,14 +131,16 @@ class Context:
 
     def dedup_batch_device(self, d_keys, d_nmask, d_freq, bucket_off, umi_len, d_kept, d_root=0,
                            k=1, percentage=0.5, algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0,
-                           stream=0):
-        """Device-pointer batched call (integers = device addresses, e.g. tensor.data_ptr())."""
+                           stream=0, d_bucket_off=0):
+        """Device-pointer batched call (integers = device addresses, e.g. tensor.data_ptr()).
+        d_bucket_off: device copy of bucket_off, if the caller keeps one (no upload inside)."""
         bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
         st = Stats()
-        check(load().umi_dedup_batch_device(self._h, d_keys, d_nmask or None, d_freq,
-                                            ptr(bucket_off, C.c_uint64), len(bucket_off) - 1,
-                                            umi_len, k, percentage, algo, adj_max_freq, d_kept,
-                                            d_root or None, stream or None, C.byref(st)))
+        check(load().umi_dedup_batch_device_table(self._h, d_keys, d_nmask or None, d_freq,
+                                                  ptr(bucket_off, C.c_uint64), d_bucket_off or None,
+                                                  len(bucket_off) - 1, umi_len, k, percentage, algo,
+                                                  adj_max_freq, d_kept, d_root or None, stream or None,
+                                                  C.byref(st)))
         return st.as_dict()
 
 

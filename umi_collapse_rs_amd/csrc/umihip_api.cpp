@@ -293,12 +293,17 @@ class Pipeline {
     }
 
     uint64_t edge_count() const { return n_edges; }
+    // the caller keeps a copy of bucket_off in device memory (resident like keys and freq): no
+    // staging copy, no upload
+    void use_device_table(const uint64_t *d_table) { d_boff_caller = d_table; }
 
   private:
     umi_ctx *ctx;
     const uint64_t *d_keys, *d_nmask;
     const int32_t *d_freq;
     const uint64_t *bucket_off;
+    const uint64_t *d_boff_caller = nullptr;
+    const uint64_t *d_boff() const { return d_boff_caller ? d_boff_caller : ctx->boff.as<uint64_t>(); }
     uint64_t n_buckets;
     uint32_t n;
     int umi_len, k;
@@ -553,18 +558,27 @@ class Pipeline {
         for (uint64_t c = 0; c < pieces; c++) {
             const uint64_t b0 = n_buckets * c / pieces, b1 = n_buckets * (c + 1) / pieces;
             uint64_t prev = bucket_off[b0], back = 0;
-            for (uint64_t b = b0; b < b1; b++) {
-                const uint64_t v = bucket_off[b + 1];
-                back |= v < prev;
-                ctx->h_boff[b + 1] = prev = v;
+            if (d_boff_caller) { // (the table is on the device already: nothing to copy)
+                for (uint64_t b = b0; b < b1; b++) {
+                    const uint64_t v = bucket_off[b + 1];
+                    back |= v < prev;
+                    prev = v;
+                }
+            } else {
+                for (uint64_t b = b0; b < b1; b++) {
+                    const uint64_t v = bucket_off[b + 1];
+                    back |= v < prev;
+                    ctx->h_boff[b + 1] = prev = v;
+                }
             }
             if (back) {
                 for (uint64_t b = b0; b < b1; b++)
                     if (bucket_off[b + 1] < bucket_off[b])
                         return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
             }
-            HIP_TRY(hipMemcpyAsync(ctx->boff.as<uint64_t>() + b0, ctx->h_boff + b0, (b1 - b0 + 1) * 8,
-                                   hipMemcpyHostToDevice, s));
+            if (!d_boff_caller)
+                HIP_TRY(hipMemcpyAsync(ctx->boff.as<uint64_t>() + b0, ctx->h_boff + b0, (b1 - b0 + 1) * 8,
+                                       hipMemcpyHostToDevice, s));
             int rc;
             if (fuse && b1 > b0 && (rc = fused_stage(b0, b1))) return rc;
         }
@@ -576,8 +590,8 @@ class Pipeline {
     {
         if (fused_max < 1 || b1 <= b0) return UMI_OK;
         if (prof && !fused_ran) HIP_TRY(hipEventRecord(ctx->ev[5], s));
-        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, percentage, ctx->boff.as<uint64_t>() + b0,
-                                     (uint32_t)(b1 - b0), fused_max, ctx->label.as<uint32_t>(), d_kept,
+        HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, percentage, d_boff() + b0,
+                                     (uint32_t)(b1 - b0), fused_max, n, ctx->label.as<uint32_t>(), d_kept,
                                      d_root, k, umi_len, ctx->fused_sliced, mode, adj_max_freq, d_cnt, s));
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[6], s));
         if (!fused_ran) st.n_pair_launches += 1;
@@ -589,7 +603,7 @@ class Pipeline {
     // the entries of a segment also count themselves into the bins of its parts
     int prep_stage()
     {
-        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, ctx->boff.as<uint64_t>(), n_buckets, d_ranges,
+        HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, d_boff(), n_buckets, d_ranges,
                             (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
                             ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), nullptr, d_cnt,
                             seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
@@ -1131,11 +1145,13 @@ class EdgeCollapse {
 int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                  const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
                  int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
-                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats)
+                 uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats,
+                 const uint64_t *d_bucket_off = nullptr)
 {
-    return Pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, n, umi_len, k, percentage,
-                    mode, adj_max_freq, d_kept, d_root, s)
-        .run(stats);
+    Pipeline p(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, n, umi_len, k, percentage, mode, adj_max_freq,
+               d_kept, d_root, s);
+    p.use_device_table(d_bucket_off);
+    return p.run(stats);
 }
 
 
@@ -1750,6 +1766,16 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
                            int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
                            uint8_t *d_kept, uint32_t *d_root, void *hip_stream, umi_stats *stats)
 {
+    return umi_dedup_batch_device_table(ctx, d_keys, d_nmask, d_freq, bucket_off, nullptr, n_buckets, umi_len, k,
+                                        percentage, algo, adj_max_freq, d_kept, d_root, hip_stream, stats);
+}
+
+int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                                 const int32_t *d_freq, const uint64_t *bucket_off, const uint64_t *d_bucket_off,
+                                 uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
+                                 int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root, void *hip_stream,
+                                 umi_stats *stats)
+{
     if (ctx && !ctx->subs.empty()) {
         if (ctx->subs.size() > 1)
             return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
@@ -1769,7 +1795,7 @@ int umi_dedup_batch_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t 
     return run_pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len,
                         k, percentage,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
-                        adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats);
+                        adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats, d_bucket_off);
 }
 
 int umi_pairs_partial_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,

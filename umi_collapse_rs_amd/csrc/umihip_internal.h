@@ -346,7 +346,7 @@ hipError_t gather_keys(const void *keys, bool key32, const uint32_t *pos, uint32
 // sliced: use the bit-sliced body when k <= 3
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *kept, uint32_t *root,
+                                uint32_t fused_max, uint32_t n_entries, uint32_t *label, uint8_t *kept, uint32_t *root,
                                 int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
                                 unsigned long long *counters, hipStream_t s);
 

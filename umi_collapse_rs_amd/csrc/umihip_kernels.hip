@@ -102,13 +102,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
 __global__ __launch_bounds__(256) void bucket_rise_kernel(const int32_t *__restrict__ freq,
                                                           const uint64_t *__restrict__ bucket_off,
                                                           uint64_t n_buckets, uint32_t fused_max,
+                                                          uint32_t n_entries,
                                                           unsigned long long *__restrict__ counters)
 {
     unsigned int rises = 0;
     for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets;
          b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
-        if (s > 0 && s < e && e - s > fused_max) rises += freq[s] > freq[s - 1] ? 1u : 0u;
+        if (s > 0 && s < e && e <= (uint64_t)n_entries && e - s > fused_max) rises += freq[s] > freq[s - 1] ? 1u : 0u;
     }
     block_count_add(rises, &counters[CNT_START_RISES]);
 }
@@ -1733,17 +1734,21 @@ __device__ __forceinline__ FusedCounts small_bucket_body_bs(const uint64_t *__re
         for (int h = 0; h < H; h++)
 #pragma unroll
             for (int l = 0; l <= K; l++) cnt[s][h][l] = 0u;
+    uint64_t cur[RL]; // the folded key, shifted down a base per trip
+#pragma unroll
+    for (int s = 0; s < RL; s++) cur[s] = fold[s];
     for (int i = 0; i < umi_len; i++) {
-        uint32_t r0[RL], r1[RL]; // this row's two code bits of base i, spread over a word
+        uint32_t r0[RL], r1[RL]; // this row's two code bits of base i, spread over a word (one v_bfe_i32 each)
 #pragma unroll
         for (int s = 0; s < RL; s++) {
-            r0[s] = 0u - (uint32_t)((fold[s] >> (3 * i)) & 1ull);
-            r1[s] = 0u - (uint32_t)((fold[s] >> (3 * i + 1)) & 1ull);
+            r0[s] = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)cur[s], 0u, 1u);
+            r1[s] = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)cur[s], 1u, 1u);
+            cur[s] >>= 3;
         }
 #pragma unroll
         for (int w = 0; w < RL; w++) {
-            const unsigned long long p0 = __ballot((int)(r0[w] & 1u));
-            const unsigned long long p1 = __ballot((int)(r1[w] & 1u));
+            const unsigned long long p0 = __ballot(r0[w] != 0u);
+            const unsigned long long p1 = __ballot(r1[w] != 0u);
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
                 const uint32_t c0 = (uint32_t)(p0 >> (32 * hh)), c1 = (uint32_t)(p1 >> (32 * hh));
@@ -1866,6 +1871,23 @@ __device__ __forceinline__ FusedCounts small_bucket_body_bs(const uint64_t *__re
         alive[s] = 0u;
     }
     if (MODE == MODE_DIRECTIONAL) {
+        // A sweep visits the sources in rank order.  If no row has an in-edge from a source of
+        // larger rank, every source's label is final when its turn comes and one sweep is the
+        // fixed point; such an edge needs freq[row] <= thr[source] with the source ranked behind
+        // the row: at p = 0.5 two freq-1 UMIs next to each other, rare in a position.  Otherwise
+        // the sweeps go on until one moves nothing.
+        bool back = false;
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            const int row = lane + 64 * s;
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                const int above = row - 32 * h + 1; // columns of this half from here on rank behind the row
+                const uint32_t m = above <= 0 ? 0xFFFFFFFFu : (above >= 32 ? 0u : ~((1u << above) - 1u));
+                back |= (in[s][h] & m) != 0u;
+            }
+        }
+        const bool iterate = __any(back);
         bool changed;
         do { // Gauss-Seidel sweeps in rank order over the active sources until no label moves
             uint32_t before[RL];
@@ -1886,7 +1908,7 @@ __device__ __forceinline__ FusedCounts small_bucket_body_bs(const uint64_t *__re
             changed = false;
 #pragma unroll
             for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
-        } while (__any(changed));
+        } while (iterate && __any(changed));
     } else {
 #pragma unroll
         for (int s = 0; s < RL; s++) alive[s] = 1u;
@@ -1926,6 +1948,7 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
                                                            float percentage,
                                                            const uint64_t *__restrict__ bucket_off,
                                                            uint32_t n_buckets, uint32_t fused_max,
+                                                           uint32_t n_entries,
                                                            uint32_t *__restrict__ label,
                                                            uint8_t *__restrict__ kept,
                                                            uint32_t *__restrict__ root, int k,
@@ -1937,9 +1960,16 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
     const int lane = threadIdx.x & 63;
     unsigned int bad = 0, n_kept = 0; // per lane; summed over the block at the end
     for (uint32_t b = wave; b < n_buckets; b += n_waves) {
-        const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b]);
-        const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)bucket_off[b + 1]);
+        const uint64_t s64 = bucket_off[b], e64 = bucket_off[b + 1];
+        const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)s64);
+        const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)e64);
         const uint32_t n = end - start;
+        // (a table in device memory is the caller's: one that does not match the host's copy -- which
+        // is the one that was checked -- must not lead outside the arrays)
+        if (e64 < s64 || e64 > (uint64_t)n_entries) {
+            bad += lane == 0 ? 1u : 0u;
+            continue;
+        }
         if (n == 0 || n > fused_max) continue;
         if (n == 1) { // a position with one UMI: it survives
             if (lane == 0) {
@@ -2222,7 +2252,7 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
                                                                      label, lab, counters, segs, n_seg_parts,
                                                                      bin_cnt);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
-                                                                     ranges ? fused_max : 0u, counters);
+                                                                     ranges ? fused_max : 0u, n, counters);
     return hipGetLastError();
 }
 
@@ -2359,13 +2389,13 @@ namespace {
 template <bool HAS_N, int MODE>
 void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_t *nmask,
                     const int32_t *freq, float percentage, const uint64_t *bucket_off,
-                    uint32_t n_buckets, uint32_t fused_max, uint32_t *label, uint8_t *kept,
+                    uint32_t n_buckets, uint32_t fused_max, uint32_t n_entries, uint32_t *label, uint8_t *kept,
                     uint32_t *root, int k, int umi_len, int32_t adj_max_freq,
                     unsigned long long *counters, hipStream_t s)
 {
 #define UMI_LAUNCH_SMALL(KB)                                                                          \
     small_bucket_kernel<HAS_N, MODE, KB><<<blocks, 256, 0, s>>>(keys, nmask, freq, percentage, bucket_off, \
-                                                                n_buckets, fused_max, label, kept, root, k, \
+                                                                n_buckets, fused_max, n_entries, label, kept, root, k, \
                                                                 umi_len, adj_max_freq, counters)
     switch (kb) {
     case 0: UMI_LAUNCH_SMALL(0); break;
@@ -2382,7 +2412,7 @@ void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_
 // label, kept mask, root, survivor count.
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
-                                uint32_t fused_max, uint32_t *label, uint8_t *kept, uint32_t *root,
+                                uint32_t fused_max, uint32_t n_entries, uint32_t *label, uint8_t *kept, uint32_t *root,
                                 int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
                                 unsigned long long *counters, hipStream_t s)
 {
@@ -2390,11 +2420,11 @@ hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, con
     const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, 256 * 8);
     const int kb = (sliced && k >= 0 && k <= 3) ? k : -1;
     if (mode == MODE_DIRECTIONAL) {
-        if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
-        else launch_small_k<false, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, n_entries, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        else launch_small_k<false, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, n_entries, label, kept, root, k, umi_len, adj_max_freq, counters, s);
     } else {
-        if (nmask) launch_small_k<true, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
-        else launch_small_k<false, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        if (nmask) launch_small_k<true, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, n_entries, label, kept, root, k, umi_len, adj_max_freq, counters, s);
+        else launch_small_k<false, MODE_ADJACENCY>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, n_entries, label, kept, root, k, umi_len, adj_max_freq, counters, s);
     }
     return hipGetLastError();
 }
