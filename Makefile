@@ -27,8 +27,7 @@ $(LIB): $(OBJS)
 
 $(CLI): $(LIB) $(PKG)/host/umicollapse_main.cpp $(PKG)/host/bam.hpp $(PKG)/host/bgzf.hpp include/umihip.h
 	mkdir -p $(PKG)/bin
-	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/umicollapse_main.cpp -L$(PKG) -lumihip -lz -lpthread \
-	    -Wl,-rpath,'$$ORIGIN/..'
+	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/umicollapse_main.cpp -lz -lpthread -ldl
 
 cli: $(CLI)
 

@@ -21,7 +21,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "head"
 P = os.path.join(ROOT, "gpurun_out", "prof_r02")
 STEPS = 7  # --steps 5 --warmup 2 of tools/profile_r02.sh
 
-PHASES = (("prep", ("prep_kernel", "bucket_rise", "seg_scan", "seg_scatter", "seg_hist", "iota", "rocprim",
+PHASES = (("prep", ("prep_kernel", "bucket_rise", "seg_scan", "seg_scatter", "seg_count", "seg_hist", "iota", "rocprim",
                     "build_planes", "gather_kernel")),
           ("pairs", ("seg_pair", "seg_edge", "pair_kernel", "bs_pair", "bs_run", "bs_tab", "tab_scan",
                      "verify_list", "small_bucket")),

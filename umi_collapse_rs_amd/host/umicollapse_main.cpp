@@ -19,8 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <future>
 #include <string>
+#include <unistd.h>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -54,6 +56,69 @@ struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
     std::fprintf(stderr, "umicollapse: %s\n", msg.c_str());
     std::fflush(stderr);
     std::_Exit(101); // (no static destructors: the GPU's start-up thread may still be running)
+}
+
+// libumihip.so is opened by hand, on the side thread that wakes the GPU: mapping the library and
+// the HIP runtime it brings along (static initialisers, the code objects' registration) takes
+// ~0.15 s before main() of a process that otherwise lives 0.45 s, and the first thing the
+// program does -- reading and inflating the input -- needs none of it.
+struct HipLib {
+    void *handle = nullptr;
+    int (*ctx_create_multi)(const int *, int, umi_ctx **) = nullptr;
+    int (*ctx_set_option)(umi_ctx *, const char *, int64_t) = nullptr;
+    const char *(*last_error)(void) = nullptr;
+    int (*stage_reads)(umi_ctx *, const uint64_t *, int, const uint8_t *, const int32_t *, uint64_t, int, int,
+                       uint64_t *, uint64_t *, int32_t *, uint64_t *, uint64_t *, uint64_t *, uint64_t *) = nullptr;
+    int (*dedup_batch)(umi_ctx *, const uint64_t *, const uint64_t *, const int32_t *, const uint64_t *, uint64_t, int,
+                       int, float, int, int32_t, uint8_t *, uint32_t *, umi_stats *) = nullptr;
+    std::string error;
+    bool load()
+    {
+        if (handle) return true;
+        char exe[4096];
+        const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+        std::string dir = n > 0 ? std::string(exe, (size_t)n) : std::string(".");
+        dir = dir.substr(0, dir.find_last_of('/'));
+        const std::string path = dir + "/../libumihip.so"; // bin/umicollapse beside the package's library
+        handle = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!handle) {
+            error = std::string("cannot load ") + path + ": " + dlerror() + " (there is no CPU path)";
+            return false;
+        }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(handle, name);
+            if (!p && error.empty()) error = std::string("libumihip.so lacks ") + name;
+            return p;
+        };
+        ctx_create_multi = (decltype(ctx_create_multi))sym("umi_ctx_create_multi");
+        ctx_set_option = (decltype(ctx_set_option))sym("umi_ctx_set_option");
+        last_error = (decltype(last_error))sym("umi_last_error");
+        stage_reads = (decltype(stage_reads))sym("umi_stage_reads");
+        dedup_batch = (decltype(dedup_batch))sym("umi_dedup_batch");
+        return error.empty();
+    }
+};
+
+// src/utils/mod.rs:63-83 with the codes of src/utils/read.rs:23-31 (the library's umi_encode_umis,
+// restated here so that the staging of the host path needs no library call)
+bool encode_umi(const uint8_t *u, size_t len, uint64_t *key, uint64_t *nmask)
+{
+    uint64_t k = 0, nm = 0;
+    for (size_t b = 0; b < len; b++) {
+        uint64_t c;
+        switch (u[b]) {
+        case 'A': c = 0; break;
+        case 'T': c = 5; break;
+        case 'C': c = 6; break;
+        case 'G': c = 3; break;
+        case 'N': c = 4; nm |= 7ull << (3 * b); break;
+        default: return false;
+        }
+        k |= c << (3 * b);
+    }
+    *key = k;
+    *nmask = nm;
+    return true;
 }
 
 void usage()
@@ -209,13 +274,18 @@ int main(int argc, char **argv)
     // library's kernels (their code objects are loaded then) take ~0.1 s of a process that lives
     // half a second, none of it on the device.  A tiny staging call and a tiny batch go through;
     // whoever needs the context first waits for this thread.
+    HipLib lib;
     std::future<umi_ctx *> warm;
     std::string warm_error;
     if (!args.passthrough && args.dump_staging.empty())
         warm = std::async(std::launch::async, [&]() -> umi_ctx * {
             umi_ctx *c = nullptr;
-            if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &c) != UMI_OK) {
-                warm_error = umi_last_error();
+            if (!lib.load()) {
+                warm_error = lib.error;
+                return nullptr;
+            }
+            if (lib.ctx_create_multi(args.devices.data(), (int)args.devices.size(), &c) != UMI_OK) {
+                warm_error = lib.last_error();
                 return nullptr;
             }
             const uint64_t akey[2] = {0, 0};
@@ -224,9 +294,9 @@ int main(int argc, char **argv)
             int32_t fr[2];
             uint8_t kept[2];
             umi_stats wst;
-            if (umi_stage_reads(c, akey, 1, umis, nullptr, 2, 4, 0, k, nm, fr, rp, off, &ne, &nbk) != UMI_OK ||
-                umi_dedup_batch(c, k, nullptr, fr, off, nbk, 4, 1, 0.5f, UMI_ALGO_DIRECTIONAL, 0, kept, nullptr, &wst) != UMI_OK)
-                warm_error = umi_last_error(); // (reported when the real call fails the same way)
+            if (lib.stage_reads(c, akey, 1, umis, nullptr, 2, 4, 0, k, nm, fr, rp, off, &ne, &nbk) != UMI_OK ||
+                lib.dedup_batch(c, k, nullptr, fr, off, nbk, 4, 1, 0.5f, UMI_ALGO_DIRECTIONAL, 0, kept, nullptr, &wst) != UMI_OK)
+                warm_error = lib.last_error(); // (reported when the real call fails the same way)
             return c;
         });
 
@@ -303,7 +373,7 @@ int main(int argc, char **argv)
                 if (!sp) err = "failed to get the umi";
                 else if (umi_length == 0) err = "Empty UMI sequence extracted";
                 else if (at + umi_length > qn) err = "UMI runs past the end of the read name";
-                else if (umi_encode_umis(q + at, 1, (int)umi_length, &ii.key, &ii.nmask) != UMI_OK) err = umi_last_error();
+                else if (!encode_umi(q + at, umi_length, &ii.key, &ii.nmask)) err = "Unknown character in UMI sequence"; // utils/mod.rs:77-79
                 if (err) {
                     ii.state = 2;
                     if (first_error[t] == UINT32_MAX) { first_error[t] = ri; errors[t] = err; }
@@ -351,8 +421,9 @@ int main(int argc, char **argv)
             if (warm.valid()) {
                 ctx = warm.get();
                 if (!ctx) die(warm_error);
-            } else if (umi_ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) {
-                die(umi_last_error());
+            } else {
+                if (!lib.load()) die(lib.error);
+                if (lib.ctx_create_multi(args.devices.data(), (int)args.devices.size(), &ctx) != UMI_OK) die(lib.last_error());
             }
             t_init += now_s() - t0;
         };
@@ -388,9 +459,9 @@ int main(int argc, char **argv)
                 need_ctx();
                 keys.assign(ns, 0); nmask.assign(ns, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
                 uint64_t ne = 0, nbk = 0;
-                if (umi_stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, merge != 0 ? 1 : 0,
+                if (lib.stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, merge != 0 ? 1 : 0,
                                     keys.data(), nmask.data(), freq.data(), rep64.data(), off.data(), &ne, &nbk) != UMI_OK)
-                    die(umi_last_error());
+                    die(lib.last_error());
                 n = (size_t)ne;
                 nb = (size_t)nbk;
                 keys.resize(n); nmask.resize(n); freq.resize(n); off.resize(nb + 1);
@@ -504,16 +575,16 @@ int main(int argc, char **argv)
             // (deduplicate_sam.rs:210-213), so the result is the same for all of them.  Here
             // "naive" is the plain all-pairs tile walk; any other value (the default is
             // "ngrambktree") adds the exact range pruning of key-sorted tiles on deep positions.
-            if (umi_ctx_set_option(ctx, "prune", args.data != "naive") != UMI_OK) die(umi_last_error());
+            if (lib.ctx_set_option(ctx, "prune", args.data != "naive") != UMI_OK) die(lib.last_error());
             t_gpu0 = now_s();
-            if (umi_dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
+            if (lib.dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
                                 (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
                                 kept.data(), args.track_clusters ? root.data() : nullptr, &st) != UMI_OK)
-                die(umi_last_error());
+                die(lib.last_error());
             t_gpu1 = now_s();
         }
-        if (!ctx && warm.valid()) ctx = warm.get(); // (nothing to do for the GPU: still to be put away)
-        if (ctx) umi_ctx_destroy(ctx);
+        // (the context is not put away: tearing the HIP runtime down costs a process that lives half
+        // a second another 0.1 s, and the process ends below without running destructors)
         // --tag: cluster id / size per entry from the root of every entry.  Survivors in index
         // order are the roots in the order ClusterTracker::track sees them (bucket by bucket,
         // rank order inside), so offset + idx (cluster_tracker.rs:88-100, deduplicate_sam.rs:215)
@@ -634,5 +705,7 @@ int main(int argc, char **argv)
     } catch (const std::exception &e) {
         die(e.what());
     }
-    return 0;
+    if (warm.valid()) warm.wait(); // (a file without staged reads: the start-up thread may still be at it)
+    std::fflush(nullptr);
+    std::_Exit(0); // the output file is closed; device memory and the runtime go with the process
 }
