@@ -7,7 +7,7 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unuse
 
 LIB := $(PKG)/libumihip.so
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_sort.o $(OBJDIR)/umihip_api.o
+OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_wide.o $(OBJDIR)/umihip_sort.o $(OBJDIR)/umihip_api.o
 HDRS := $(CSRC)/umihip_internal.h $(CSRC)/umihip_device.h $(CSRC)/umihip_plan.hpp include/umihip.h
 CLI := $(PKG)/bin/umicollapse
 

@@ -38,6 +38,7 @@ extern "C" {
 #define UMI_ALGO_ADJACENCY 1   /* src/algo/adjacency.rs  */
 
 #define UMI_MAX_UMI_LEN 21 /* one 64-bit word per key (3 bits per base) */
+#define UMI_MAX_WIDE_UMI_LEN 85 /* the _wide entry points: up to 4 words per key */
 
 typedef struct umi_ctx umi_ctx;   /* one per process/GPU; not re-entrant (the reference calls
                                      apply strictly sequentially, deduplicate_sam.rs:207) */
@@ -131,6 +132,25 @@ int umi_abi_version(void);
  * panics. */
 int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys,
                     uint64_t *nmask);
+
+/* ---- keys of more than one word (umi_len 22..UMI_MAX_WIDE_UMI_LEN): BitSet.bits as
+ *      n_words = ceil(3 * umi_len / 64) words per key, entry-major (keys[i * n_words + w] =
+ *      bits[w] of entry i; nmask likewise or NULL), everything else as in umi_dedup_batch.  The
+ *      distance is the reference's per-word arithmetic (src/utils/bitset.rs:77-91), a base that
+ *      straddles two words included.  Every pair of a position is evaluated exactly (no filter,
+ *      no n-gram partition): no BASELINE config has such UMIs.  umi_encode_umis_wide is to_bitset
+ *      (src/utils/mod.rs:63-83) for these lengths, host code. */
+int umi_encode_umis_wide(const uint8_t *ascii, uint64_t n, int umi_len, int n_words, uint64_t *keys,
+                         uint64_t *nmask);
+int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words,
+                         const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets,
+                         int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
+                         uint8_t *kept, uint32_t *root, umi_stats *stats);
+int umi_dedup_batch_wide_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                                int n_words, const int32_t *d_freq, const uint64_t *bucket_off,
+                                uint64_t n_buckets, int umi_len, int k, float percentage, int algo,
+                                int32_t adj_max_freq, uint8_t *d_kept, uint32_t *d_root,
+                                void *hip_stream, umi_stats *stats);
 
 /* ---- read staging on the device: the per-read part of
  *      DeduplicateSAM::deduplicate_and_merge, src/deduplicate_sam.rs:148-176

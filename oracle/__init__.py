@@ -64,6 +64,9 @@ def lib():
         L.orc_dedup_batch.argtypes = [u64p, u64p, i32p, u64p, C.c_uint64, C.c_int, C.c_int32,
                                       C.c_float, C.c_int, C.c_int32, u8p, u32p, u64p]
         L.orc_dedup_batch.restype = C.c_int
+        L.orc_dedup_batch_wide.argtypes = [u64p, u64p, C.c_int, i32p, u64p, C.c_uint64, C.c_int, C.c_int32,
+                                           C.c_float, C.c_int, C.c_int32, u8p, u32p, C.POINTER(C.c_uint64)]
+        L.orc_dedup_batch_wide.restype = C.c_int
         L.orc_stage_reads.argtypes = [u32p, u8p, i32p, C.c_uint64, C.c_int, C.c_int, u64p, u64p,
                                       i32p, u64p, u64p, u64p, u64p]
         L.orc_stage_reads.restype = C.c_int
@@ -192,6 +195,41 @@ def dedup_batch(keys, nmask, freq, bucket_off, umi_len, k, percentage=0.5, algo=
                                _p(root, C.c_uint32), C.byref(calls))
     if rc != 0:
         raise ValueError("orc_dedup_batch failed: %d" % rc)
+    return kept[:n], root[:n], int(calls.value)
+
+
+def encode_keys_wide(umis):
+    """list of ASCII UMIs of one length (any, up to 85 bp) -> (keys, nmask) uint64 [n, n_words]
+    through the restated to_bitset."""
+    first = to_bitset(umis[0])
+    w = first.nwords
+    keys = np.zeros((len(umis), w), dtype=np.uint64)
+    nm = np.zeros((len(umis), w), dtype=np.uint64)
+    for i, u in enumerate(umis):
+        b = to_bitset(u)
+        assert b.nwords == w
+        for j in range(w):
+            keys[i, j] = b.bits[j]
+            nm[i, j] = b.nbits[j] if b.has_n else 0
+    return keys, nm
+
+
+def dedup_batch_wide(keys, nmask, freq, bucket_off, umi_len, k, percentage=0.5, algo=0, adj_max_freq=0):
+    """Batched oracle for keys of several words: keys / nmask uint64 [N, n_words]."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n, w = keys.shape
+    freq = np.ascontiguousarray(freq, dtype=np.int32)
+    bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+    nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+    kept = np.ones(max(1, n), dtype=np.uint8)
+    root = np.arange(max(1, n), dtype=np.uint32)
+    calls = C.c_uint64(0)
+    rc = lib().orc_dedup_batch_wide(_p(keys, C.c_uint64), _p(nm, C.c_uint64), w, _p(freq, C.c_int32),
+                                    _p(bucket_off, C.c_uint64), len(bucket_off) - 1, umi_len, k,
+                                    percentage, algo, adj_max_freq, _p(kept, C.c_uint8),
+                                    _p(root, C.c_uint32), C.byref(calls))
+    if rc != 0:
+        raise ValueError("orc_dedup_batch_wide failed: %d" % rc)
     return kept[:n], root[:n], int(calls.value)
 
 

@@ -251,14 +251,14 @@ uint32_t orc_adjacency_apply(const orc_bitset *umis, const int32_t *freq, uint32
     return n_out;
 }
 
-int orc_dedup_batch(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int32_t k,
-                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept,
-                    uint32_t *root, uint64_t *dist_calls)
+int orc_dedup_batch_wide(const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                         const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int32_t k,
+                         float percentage, int algo, int32_t adj_max_freq, uint8_t *kept,
+                         uint32_t *root, uint64_t *dist_calls)
 {
     int total_bits = umi_len * ENCODING_LENGTH;
-    int cap = total_bits / CHUNK_SIZE + ((total_bits % CHUNK_SIZE) == 0 ? 0 : 1);
-    if (cap != 1) return -2; /* batched form carries one word per key */
+    int cap = total_bits / CHUNK_SIZE + ((total_bits % CHUNK_SIZE) == 0 ? 0 : 1); /* bitset.rs:17-18 */
+    if (cap != n_words || n_words < 1 || n_words > ORC_MAXW) return -2;
     for (uint64_t b = 0; b < n_buckets; b++) { /* deduplicate_sam.rs:207 */
         uint64_t s = bucket_off[b], e = bucket_off[b + 1];
         uint32_t n = (uint32_t)(e - s);
@@ -271,11 +271,15 @@ int orc_dedup_batch(const uint64_t *keys, const uint64_t *nmask, const int32_t *
                 free(umis); free(out); free(rof);
                 return -1;
             }
-            umis[i].nwords = 1;
-            umis[i].bits[0] = keys[s + i];
-            if (nmask && nmask[s + i]) {
+            umis[i].nwords = n_words;
+            int any_n = 0;
+            for (int w = 0; w < n_words; w++) {
+                umis[i].bits[w] = keys[(s + i) * (uint64_t)n_words + w];
+                if (nmask && nmask[(s + i) * (uint64_t)n_words + w]) any_n = 1;
+            }
+            if (any_n) { /* n_bits is Some(..) only for a UMI with an N (utils/mod.rs:74-76) */
                 umis[i].has_n = 1;
-                umis[i].nbits[0] = nmask[s + i];
+                for (int w = 0; w < n_words; w++) umis[i].nbits[w] = nmask[(s + i) * (uint64_t)n_words + w];
             }
             rof[i] = i;
         }
@@ -294,6 +298,15 @@ int orc_dedup_batch(const uint64_t *keys, const uint64_t *nmask, const int32_t *
         free(rof);
     }
     return 0;
+}
+
+int orc_dedup_batch(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                    const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int32_t k,
+                    float percentage, int algo, int32_t adj_max_freq, uint8_t *kept,
+                    uint32_t *root, uint64_t *dist_calls)
+{ /* the batched form with one word per key */
+    return orc_dedup_batch_wide(keys, nmask, 1, freq, bucket_off, n_buckets, umi_len, k, percentage, algo,
+                                adj_max_freq, kept, root, dist_calls);
 }
 
 /* ---- staging ----------------------------------------------------------- */

@@ -93,6 +93,14 @@ int orc_dedup_batch(const uint64_t *keys, const uint64_t *nmask /* or NULL */,
                     int umi_len, int32_t k, float percentage, int algo /* 0 dir, 1 adj */,
                     int32_t adj_max_freq, uint8_t *kept, uint32_t *root, uint64_t *dist_calls);
 
+/* The same for keys of n_words words (umi_len > 21; keys / nmask entry-major,
+ * [i * n_words + w] = bits[w] / n_bits[w] of entry i): -2 unless n_words is what
+ * BitSet::new_with_len gives for umi_len (bitset.rs:17-18). */
+int orc_dedup_batch_wide(const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                         const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int32_t k,
+                         float percentage, int algo, int32_t adj_max_freq, uint8_t *kept,
+                         uint32_t *root, uint64_t *dist_calls);
+
 /* ---- Staging: src/deduplicate_sam.rs:148-176, merge/mod.rs
  * reads arrive in file order; bucket_id[i] is the alignment-key id (first
  * appearance numbering is done by the caller), umi is umi_len ASCII bytes per

@@ -96,3 +96,48 @@ def test_stage_reads_merge_and_order():
     assert st["rep"].tolist() == [3, 0, 5, 2]
     st_any = orc.stage_reads(bid, ub, score, 4, merge=0)
     assert st_any["rep"].tolist() == [1, 0, 5, 2]
+
+
+@pytest.mark.parametrize("L,k,n_frac", [(22, 1, 0.0), (22, 2, 0.03), (30, 1, 0.02), (42, 3, 0.01)])
+def test_multi_word_keys_match_bruteforce(L, k, n_frac):
+    """UMIs of 22..42 bases: two words per key.  Below 43 bases at most one base straddles two
+    words, and bit_count_xor's per-word popcount(x)/3 (bitset.rs:85-87) still gives the
+    5-letter Hamming distance after the final /2 -- the character-level model applies.  Both the
+    per-bucket apply and the batched multi-word form."""
+    rng = np.random.default_rng(50 * L + k)
+    keys, nm, fr, off, expect = [], [], [], [0], []
+    for trial in range(8):
+        umis, freq = random_bucket(rng, n_mol=int(rng.integers(1, 40)), L=L, err=0.06, n_frac=n_frac)
+        if n_frac and len(umis) > 2:  # an N exactly at the straddling base
+            umis[0] = umis[0][:21] + "N" + umis[0][22:]
+            if len(set(umis)) != len(umis):
+                continue
+        surv, root_of, _ = orc.apply_strings(umis, freq, k, "dir", 0.5)
+        bs, br = brute_directional(umis, freq, k, 0.5)
+        assert surv == bs and root_of == br
+        cu, cf, _ = canonical(umis, freq)
+        kk, nn = orc.encode_keys_wide(cu)
+        assert kk.shape[1] == 2
+        keys.append(kk); nm.append(nn); fr.extend(cf)
+        off.append(off[-1] + len(cu))
+        s2, _ = brute_directional(cu, cf, k, 0.5)
+        m = np.zeros(len(cu), np.uint8); m[s2] = 1
+        expect.append(m)
+    kept, root, _ = orc.dedup_batch_wide(np.concatenate(keys), np.concatenate(nm), fr, off, L, k)
+    assert kept.tolist() == np.concatenate(expect).tolist()
+    assert (kept == (root == np.arange(len(kept)))).all()
+
+
+def test_straddling_bases_quirk_of_the_reference():
+    """The two bases that straddle words within 85 bases (21: bits 63|64,65; 42: bits 126,127|128)
+    both N-mismatching: the mask bits of word 0 and word 2 (one each) are lost to popcount(x)/3,
+    the four of word 1 give 4/3 = 1, so bit_count_xor = 6 - 1 = 5 where whole bases would give 4;
+    after the final /2 the distance is still 2 -- with at most these two straddlers the quirk of
+    bitset.rs:85-87 never changes umi_dist (SURVEY.md 8a A2 expected it to, from 43 bases on)."""
+    a = "A" * 21 + "N" + "A" * 20 + "N" + "A"
+    b = "A" * 44
+    ba, bb = orc.to_bitset(a), orc.to_bitset(b)
+    assert ba.nwords == 3
+    assert orc.lib().orc_bit_count_xor(ba, bb) == 5 and orc.lib().orc_umi_dist(ba, bb) == 2
+    one = orc.to_bitset("A" * 21 + "N" + "A" * 22)
+    assert orc.lib().orc_bit_count_xor(one, bb) == 3 and orc.lib().orc_umi_dist(one, bb) == 1

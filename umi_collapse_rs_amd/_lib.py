@@ -47,6 +47,12 @@ SIGNATURES = {
     "umi_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "umi_abi_version": (C.c_int, []),
     "umi_encode_umis": (C.c_int, [_u8p, C.c_uint64, C.c_int, _u64p, _u64p]),
+    "umi_encode_umis_wide": (C.c_int, [_u8p, C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
+    "umi_dedup_batch_wide": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int, _i32p, _u64p, C.c_uint64, C.c_int,
+                                       C.c_int, C.c_float, C.c_int, C.c_int32, _u8p, _u32p, C.POINTER(Stats)]),
+    "umi_dedup_batch_wide_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _u64p,
+                                              C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "umi_stage_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, _u64p, _u64p, C.c_void_p]),

@@ -37,6 +37,17 @@ def to_bitset(umis, umi_len=None):
     return keys, nmask
 
 
+def to_bitset_wide(umis, umi_len):
+    """to_bitset (src/utils/mod.rs:63-83) for UMIs of any length up to 85: (keys, nmask) uint64 [n, n_words]."""
+    w = (3 * umi_len + 63) // 64
+    buf = np.frombuffer("".join(umis).encode(), dtype=np.uint8)
+    keys = np.zeros((len(umis), w), dtype=np.uint64)
+    nm = np.zeros((len(umis), w), dtype=np.uint64)
+    check(load().umi_encode_umis_wide(ptr(buf, C.c_uint8), len(umis), umi_len, w, ptr(keys, C.c_uint64),
+                                      ptr(nm, C.c_uint64)))
+    return keys, nm
+
+
 def partition_buckets(bucket_off, n_ranks):
     """umi_partition_buckets: owner rank of every bucket (uint32[n_buckets]), the assignment the
     multi-device context uses -- for hosts that run one process per GPU."""
@@ -98,6 +109,23 @@ class Context:
                                      adj_max_freq, ptr(kept, C.c_uint8), ptr(root, C.c_uint32),
                                      C.byref(st)))
         return kept, root, st.as_dict()
+
+    def dedup_batch_wide(self, keys, nmask, freq, bucket_off, umi_len, k=1, percentage=0.5,
+                         algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0, want_root=True):
+        """Batched call for keys of several words (umi_len > 21): keys / nmask uint64 [N, n_words]."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        n, w = keys.shape
+        nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+        freq = np.ascontiguousarray(freq, dtype=np.int32)
+        bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+        kept = np.zeros(max(1, n), dtype=np.uint8)
+        root = np.zeros(max(1, n), dtype=np.uint32) if want_root else None
+        st = Stats()
+        check(load().umi_dedup_batch_wide(self._h, ptr(keys, C.c_uint64), ptr(nm, C.c_uint64), w,
+                                          ptr(freq, C.c_int32), ptr(bucket_off, C.c_uint64), len(bucket_off) - 1,
+                                          umi_len, k, percentage, algo, adj_max_freq, ptr(kept, C.c_uint8),
+                                          ptr(root, C.c_uint32), C.byref(st)))
+        return kept[:n], (root[:n] if want_root else None), st.as_dict()
 
     def stage_reads(self, align_key, umi_bytes, score, umi_len, merge=1, align_key_bits=64):
         """Read staging on the device (host arrays in and out): reads in file order ->

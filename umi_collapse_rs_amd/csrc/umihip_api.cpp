@@ -181,12 +181,12 @@ struct umi_ctx {
 namespace {
 
 int check_common(umi_ctx *ctx, const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
-                 int algo, uint64_t *n_out)
+                 int algo, uint64_t *n_out, int max_len = UMI_MAX_UMI_LEN)
 {
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
     if (!bucket_off) return fail(UMI_ERR_ARG, "bucket_off is NULL");
-    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
-        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (umi_len < 1 || umi_len > max_len)
+        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, max_len);
     if (k < 0) return fail(UMI_ERR_ARG, "k must be >= 0 (got %d)", k);
     if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
         return fail(UMI_ERR_ARG, "unknown algo %d", algo);
@@ -296,6 +296,9 @@ class Pipeline {
     // the caller keeps a copy of bucket_off in device memory (resident like keys and freq): no
     // staging copy, no upload
     void use_device_table(const uint64_t *d_table) { d_boff_caller = d_table; }
+    // keys of n_words > 1 words per entry (umi_len > 21): the plain exact all-pairs kernel of
+    // umihip_wide.hip takes every bucket (no fused kernel, no filter keys, no segment index)
+    void use_wide_keys(int words) { n_words = words; }
 
   private:
     umi_ctx *ctx;
@@ -303,6 +306,8 @@ class Pipeline {
     const int32_t *d_freq;
     const uint64_t *bucket_off;
     const uint64_t *d_boff_caller = nullptr;
+    int n_words = 1;
+    bool wide() const { return n_words > 1; }
     const uint64_t *d_boff() const { return d_boff_caller ? d_boff_caller : ctx->boff.as<uint64_t>(); }
     uint64_t n_buckets;
     uint32_t n;
@@ -315,7 +320,7 @@ class Pipeline {
     hipStream_t s;
     Plan &pl; // lives in the context: its vectors keep their capacity between calls
     const bool key32, need_pairs;
-    const uint32_t fused_max;
+    uint32_t fused_max; // (0 for multi-word keys)
     const bool prof;
     const uint32_t part, n_parts; // n_parts > 1: evaluate only every n_parts-th tile task, stop
                                   // after the pair kernels (multi-GPU split of one call's pairs)
@@ -352,6 +357,7 @@ class Pipeline {
     int run_stages()
     {
         int rc;
+        if (wide()) fused_max = 0;
         // The fused kernel needs nothing from the plan (it walks the bucket table itself and does
         // everything for its buckets): with many buckets it is enqueued first, and the host walks
         // the table -- tile tasks, pair counts, the entry ranges left for prep and finalize --
@@ -437,12 +443,12 @@ class Pipeline {
     {
         // (the table is monotone: upload_table has looked)
         scan_table_range(bucket_off, 0, n_buckets, fused_max, nullptr, ctx->table_pass);
-        const bool seg_on = ctx->seg_index && need_pairs && !ctx->prune;
-        build_plan(bucket_off, n_buckets, ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K,
+        const bool seg_on = ctx->seg_index && need_pairs && !ctx->prune && !wide();
+        build_plan(bucket_off, n_buckets, wide() ? 0x7FFFFFFFu : ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K && !wide(),
                    umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
                    ctx->bs_tables && key32, ctx->bs_tab_min_run, seg_on ? std::max(ctx->seg_min, 1u) : 0u, k, key32, pl,
                    &ctx->table_pass);
-        prune = ctx->prune && need_pairs && !pl.bs_buckets.empty();
+        prune = ctx->prune && need_pairs && !pl.bs_buckets.empty() && !wide();
         keep_my_share(pl.small_tasks);
         keep_my_share(pl.big_tasks);
         st.max_bucket = pl.max_bucket;
@@ -603,6 +609,12 @@ class Pipeline {
     // the entries of a segment also count themselves into the bins of its parts
     int prep_stage()
     {
+        if (wide()) {
+            HIP_TRY(launch_wide_prep(d_keys, d_nmask, d_freq, d_ranges, (uint32_t)pl.ranges.size(), n_words, umi_len,
+                                     percentage, ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), d_cnt, s));
+            HIP_TRY(launch_bucket_rise(d_freq, d_boff(), n_buckets, n, d_cnt, s));
+            return UMI_OK;
+        }
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, d_boff(), n_buckets, d_ranges,
                             (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
                             ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), nullptr, d_cnt,
@@ -816,6 +828,11 @@ class Pipeline {
             w.bs_tasks = b.bs_tasks + first;
             HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
                                     ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
+        }
+        if (wide()) { // every bucket as 64-row chunks against its later entries
+            HIP_TRY(launch_wide_pairs(a, (uint32_t)pl.small_tasks.size(), n_words, s));
+            st.n_pair_launches += pl.small_tasks.empty() ? 0 : 1;
+            return UMI_OK;
         }
         PairArgs big = a;
         big.tasks = d_big;
@@ -1146,11 +1163,12 @@ int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                  const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
                  int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
                  uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats,
-                 const uint64_t *d_bucket_off = nullptr)
+                 const uint64_t *d_bucket_off = nullptr, int n_words = 1)
 {
     Pipeline p(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, n, umi_len, k, percentage, mode, adj_max_freq,
                d_kept, d_root, s);
     p.use_device_table(d_bucket_off);
+    p.use_wide_keys(n_words);
     return p.run(stats);
 }
 
@@ -1666,6 +1684,107 @@ int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_
     if (n && (!d_kept || !d_bits)) return fail(UMI_ERR_ARG, "kept/bits is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(launch_pack_mask(d_kept, n, d_bits, (hipStream_t)hip_stream));
+    return UMI_OK;
+}
+
+// ---- multi-word keys: umi_len 22..UMI_MAX_WIDE_UMI_LEN -------------------------------------------
+namespace {
+int wide_words(int umi_len) { return (3 * umi_len + 63) / 64; } // bitset.rs:17-18
+}
+
+int umi_encode_umis_wide(const uint8_t *ascii, uint64_t n, int umi_len, int n_words, uint64_t *keys, uint64_t *nmask)
+{ // src/utils/mod.rs:63-83 for keys of any length: base i at bits 3i .. 3i+2 of the word string
+    if (!ascii || !keys) return fail(UMI_ERR_ARG, "ascii/keys is NULL");
+    if (umi_len < 1 || umi_len > UMI_MAX_WIDE_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_WIDE_UMI_LEN);
+    if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t *k = keys + i * (uint64_t)n_words, *m = nmask ? nmask + i * (uint64_t)n_words : nullptr;
+        for (int w = 0; w < n_words; w++) {
+            k[w] = 0;
+            if (m) m[w] = 0;
+        }
+        for (int b = 0; b < umi_len; b++) {
+            uint64_t c;
+            switch (ascii[i * (uint64_t)umi_len + b]) { // read.rs:23-31
+            case 'A': c = 0; break;
+            case 'T': c = 5; break;
+            case 'C': c = 6; break;
+            case 'G': c = 3; break;
+            case 'N': c = 4; break;
+            default: return fail(UMI_ERR_CHAR, "Unknown character in UMI sequence: %u (UMI %llu)",
+                                 (unsigned)ascii[i * (uint64_t)umi_len + b], (unsigned long long)i);
+            }
+            for (int j = 0; j < 3; j++) { // bit by bit: a base may straddle two words (bitset.rs:52-61)
+                const int bit = 3 * b + j;
+                if ((c >> j) & 1) k[bit >> 6] |= 1ull << (bit & 63);
+                if (c == 4 && m) m[bit >> 6] |= 1ull << (bit & 63); // set_n_bit, bitset.rs:63-75
+            }
+        }
+    }
+    return UMI_OK;
+}
+
+int umi_dedup_batch_wide_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask, int n_words,
+                                const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, int umi_len,
+                                int k, float percentage, int algo, int32_t adj_max_freq, uint8_t *d_kept,
+                                uint32_t *d_root, void *hip_stream, umi_stats *stats)
+{
+    if (ctx && !ctx->subs.empty()) ctx = ctx->subs[0]; // (multi-word keys run on the first device)
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, UMI_MAX_WIDE_UMI_LEN);
+    if (rc) return rc;
+    if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
+    if (n && (!d_keys || !d_freq || !d_kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    if (n == 0) {
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->n_buckets = n_buckets;
+        }
+        return UMI_OK;
+    }
+    return run_pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
+                        algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY, adj_max_freq, d_kept, d_root,
+                        hip_stream ? (hipStream_t)hip_stream : ctx->own_stream, stats, nullptr, n_words);
+}
+
+int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                         const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k, float percentage,
+                         int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root, umi_stats *stats)
+{
+    if (ctx && !ctx->subs.empty()) ctx = ctx->subs[0];
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, UMI_MAX_WIDE_UMI_LEN);
+    if (rc) return rc;
+    if (n_words == 1) // one word: the ordinary call
+        return umi_dedup_batch(ctx, keys, nmask, freq, bucket_off, n_buckets, umi_len, k, percentage, algo,
+                               adj_max_freq, kept, root, stats);
+    if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
+    if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    if (n == 0) {
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->n_buckets = n_buckets;
+        }
+        return UMI_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t kb = (size_t)n * 8 * (size_t)n_words;
+    if ((rc = ctx->in_keys.reserve(kb)) || (rc = ctx->in_freq.reserve(n * 4)) || (rc = ctx->out_kept.reserve(n)) ||
+        (rc = ctx->out_root.reserve(n * 4)))
+        return rc;
+    if (nmask && (rc = ctx->in_nmask.reserve(kb))) return rc;
+    hipStream_t s = ctx->own_stream;
+    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, kb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
+    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, kb, hipMemcpyHostToDevice, s));
+    rc = umi_dedup_batch_wide_device(ctx, ctx->in_keys.as<uint64_t>(), nmask ? ctx->in_nmask.as<uint64_t>() : nullptr,
+                                     n_words, ctx->in_freq.as<int32_t>(), bucket_off, n_buckets, umi_len, k, percentage,
+                                     algo, adj_max_freq, ctx->out_kept.as<uint8_t>(),
+                                     root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
+    if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return UMI_OK;
 }
 

@@ -252,6 +252,15 @@ int seg_pair_blocks_per_cu(bool key32, bool has_n, bool ckey);
 hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
                             uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s);
 
+// ---- multi-word keys (umihip_wide.hip): umi_len 22..85, n_words = 2..4 words per key, entry-major
+hipError_t launch_wide_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
+                            const RangeTask *ranges, uint32_t n_ranges, int n_words, int umi_len, float percentage,
+                            int32_t *thr, uint32_t *label, unsigned long long *counters, hipStream_t s);
+// a.tasks: rows [row0, row0 + 64) x columns [col0, col1) of one bucket; exact distance from all words
+hipError_t launch_wide_pairs(const PairArgs &a, uint32_t n_tasks, int n_words, hipStream_t s);
+hipError_t launch_bucket_rise(const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
+                              unsigned long long *counters, hipStream_t s);
+
 // ---- read staging on the device (umihip_stage.hip) ----
 size_t stage_workspace_bytes(uint32_t n_reads);
 // reads (alignment key, UMI text, score) -> entries in canonical order + bucket table, all device

@@ -2256,6 +2256,15 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
     return hipGetLastError();
 }
 
+// the rises at bucket starts alone (the multi-word path has its own entry kernel)
+hipError_t launch_bucket_rise(const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
+                              unsigned long long *counters, hipStream_t s)
+{
+    if (n_buckets == 0) return hipSuccess;
+    bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets, 0u, n, counters);
+    return hipGetLastError();
+}
+
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s)
 {
     if (n_tasks == 0) return hipSuccess;

@@ -372,6 +372,7 @@ int main(int argc, char **argv)
                 const size_t at = sp ? (size_t)(sp - q) + 1 : 0;
                 if (!sp) err = "failed to get the umi";
                 else if (umi_length == 0) err = "Empty UMI sequence extracted";
+                else if (umi_length > UMI_MAX_UMI_LEN) err = "UMIs of more than 21 bases are not handled by this program (the library's _wide calls take them)";
                 else if (at + umi_length > qn) err = "UMI runs past the end of the read name";
                 else if (!encode_umi(q + at, umi_length, &ii.key, &ii.nmask)) err = "Unknown character in UMI sequence"; // utils/mod.rs:77-79
                 if (err) {
