@@ -104,7 +104,7 @@ struct SegScanChunk {
     uint32_t bin0, nbins; // nbins <= SEG_SCAN_CHUNK
     uint32_t seg, part;
 };
-constexpr uint32_t SEG_SCAN_CHUNK = 1024;
+constexpr uint32_t SEG_SCAN_CHUNK = 256;
 // One unit of sub-bucket work: rows [row0, min(row0 + 64, end)) against columns [col0,
 // min(end, col0 + 64 * 2^e)) of the same sub-bucket (which ends at `end`), all positions in the
 // sub-bucket arrays; only pairs with row < column count.  A 64-row chunk faces nt - t tiles of 64
@@ -151,7 +151,7 @@ struct SegBlock {
     uint32_t seg, pad;
 };
 constexpr uint32_t SEG_BLOCK_THREADS = 1024;
-constexpr uint32_t SEG_BLOCK_ENTRIES = 16 * SEG_BLOCK_THREADS;
+constexpr uint32_t SEG_BLOCK_ENTRIES = 8 * SEG_BLOCK_THREADS;
 constexpr uint32_t SEG_LDS_BINS = 16384; // bins of one part the LDS path takes (64 KB of counters)
 constexpr uint32_t RANGE_CHUNK = 2048; // entries per range task (one block of 256 threads)
 
