@@ -248,8 +248,13 @@ def main():
     d_boff = torch.from_numpy(np.ascontiguousarray(boff).view(np.int64)).to(dev)  # the table is an input too
     max_n = max(sizes)
     # the kept mask travels as bits: ceil(n / 8) bytes per rank, padded to the largest slice
-    gather_in = torch.zeros((max_n + 7) // 8, dtype=torch.uint8, device=dev)
-    gather_out = torch.zeros(gather_in.numel() * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    # (two sets: the all-gather of one step runs on the collective's own stream while the next step's
+    # kernels run on this one; a set is reused two steps later, after its collective has been waited for)
+    gather_in = [torch.zeros((max_n + 7) // 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+    gather_out = [torch.zeros(gather_in[0].numel() * world, dtype=torch.uint8, device=dev) if world > 1 else None
+                  for _ in range(2)]
+    gather_work = [None, None]
+    step_no = [0]
 
     ctx = umi.Context(dev_index, profile=True)
     opts = {}
@@ -273,9 +278,19 @@ def main():
                                  d_kept.data_ptr(), 0, k=args.k, percentage=args.p,
                                  stream=stream, d_bucket_off=d_boff.data_ptr())
         if world > 1:  # all-gatherv of the kept mask: packed to bits on the device, padded all_gather
-            c.pack_mask_device(d_kept.data_ptr(), n, gather_in.data_ptr(), stream=stream)  # over RCCL/xGMI
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            if gather_work[slot] is not None:
+                gather_work[slot].wait()
+            c.pack_mask_device(d_kept.data_ptr(), n, gather_in[slot].data_ptr(), stream=stream)  # over RCCL/xGMI
+            gather_work[slot] = dist.all_gather_into_tensor(gather_out[slot], gather_in[slot], async_op=True)
         return s
+
+    def drain_gathers():
+        for i in range(2):
+            if gather_work[i] is not None:
+                gather_work[i].wait()
+                gather_work[i] = None
 
     def timed(n_steps, c=ctx):
         if world > 1:
@@ -283,6 +298,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ss = [step(c) for _ in range(n_steps)]
+        drain_gathers()  # every step's mask has arrived everywhere inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -295,9 +311,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain_gathers()
     dt, stats = timed(args.steps)
     kept_n = int(d_kept.sum().item())
     assert kept_n == stats[-1]["n_kept"]
+    if world > 1 and not split:  # this rank's slice of the gathered bit mask is its own kept mask
+        slot = (step_no[0] - 1) & 1
+        width = gather_in[0].numel()
+        mine = gather_out[slot][rank * width:(rank + 1) * width]
+        bits = ((mine[:, None] >> torch.arange(8, device=dev, dtype=torch.uint8)[None, :]) & 1).sum()
+        assert int(bits.item()) == kept_n, "gathered mask differs from the local one"
     kept_ref = d_kept.clone()
 
     extras = not args.no_extras
