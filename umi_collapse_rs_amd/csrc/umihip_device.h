@@ -239,8 +239,15 @@ __device__ __forceinline__ void st_parent(uint32_t *p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (u < v: the pair's entries in rank order)
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t u, uint32_t v)
 {
+    // First a direct try: v, if it is still the root it started as, goes under u with one access
+    // (the usual case early on, when most entries are alone; u < v keeps parents below children).
+    // Otherwise the swap returns where v points and the walk below starts from there.
+    const uint32_t seen = atomicCAS(&parent[v], v, u);
+    if (seen == v || seen == u) return;
+    v = seen;
     uint32_t pu = ld_parent(&parent[u]), pv = ld_parent(&parent[v]);
     while (pu != pv) {
         if (pu < pv) { // u is the side whose parent is the larger
