@@ -244,11 +244,10 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t u, uint32_t 
 {
     // First a direct try: v, if it is still the root it started as, goes under u with one access
     // (the usual case early on, when most entries are alone; u < v keeps parents below children).
-    // Otherwise the swap returns where v points and the walk below starts from there.
+    // Otherwise the swap has returned v's parent and the walk below starts with it.
     const uint32_t seen = atomicCAS(&parent[v], v, u);
     if (seen == v || seen == u) return;
-    v = seen;
-    uint32_t pu = ld_parent(&parent[u]), pv = ld_parent(&parent[v]);
+    uint32_t pu = ld_parent(&parent[u]), pv = seen; // (v's parent is known now)
     while (pu != pv) {
         if (pu < pv) { // u is the side whose parent is the larger
             uint32_t t = u; u = v; v = t;

@@ -469,19 +469,16 @@ __device__ __forceinline__ void uf_union_multi(uint32_t *parent, uint32_t (&u)[I
 {
     uint32_t pu[ILP], pv[ILP];
     // (u < v.)  First a direct try, as in uf_union: v, if it is still the root it started as, goes
-    // under u with one access; otherwise the walk starts from where v points.
+    // under u with one access; otherwise the swap has returned v's parent and the walk starts with it.
     uint32_t seen[ILP];
 #pragma unroll
     for (int s = 0; s < ILP; s++) seen[s] = act[s] ? atomicCAS(&parent[v[s]], v[s], u[s]) : 0u;
 #pragma unroll
-    for (int s = 0; s < ILP; s++) {
-        act[s] = act[s] && seen[s] != v[s] && seen[s] != u[s];
-        v[s] = act[s] ? seen[s] : v[s];
-    }
+    for (int s = 0; s < ILP; s++) act[s] = act[s] && seen[s] != v[s] && seen[s] != u[s];
 #pragma unroll
     for (int s = 0; s < ILP; s++) {
         pu[s] = act[s] ? ld_parent(&parent[u[s]]) : 0u;
-        pv[s] = act[s] ? ld_parent(&parent[v[s]]) : 0u;
+        pv[s] = seen[s]; // (v's parent is known now)
     }
     for (;;) {
         bool cas[ILP], any = false;
