@@ -40,6 +40,23 @@ def test_encode_matches_oracle_and_kat(kat):
         assert (k == ok).all() and (nm == onm).all()
 
 
+def test_encode_wide_matches_oracle_and_kat_g5():
+    """umi_encode_umis_wide (host code): to_bitset for 22..85 bases against the restatement, and
+    KAT G5 -- the 22-bp UMI whose last base straddles words 0 and 1."""
+    import umi_collapse_rs_amd.api as api
+    rng = np.random.default_rng(3)
+    for L in (22, 25, 42, 43, 64, 85):
+        umis = ["".join("ACGTN"[c] for c in rng.integers(0, 5, L)) for _ in range(50)]
+        k, m = api.to_bitset_wide(umis, L)
+        ok, om = orc.encode_keys_wide(umis)
+        assert k.shape[1] == (3 * L + 63) // 64 and (k == ok).all() and (m == om).all(), L
+    k, m = api.to_bitset_wide(["ACGTACGTACGTACGTACGTAN"], 22)
+    assert k[0].tolist() == [0xaf0af0af0af0af0, 0x2] and m[0].tolist() == [0x8000000000000000, 0x3]
+    with pytest.raises(umi.UmiHipError) as e:
+        api.to_bitset_wide(["ACGTACGTACGTACGTACGTAx"], 22)
+    assert e.value.code == _lib.UMI_ERR_CHAR
+
+
 def test_encode_error_behaviour():
     # reference: panic on anything outside ATCGN (utils/mod.rs:77-79)
     with pytest.raises(umi.UmiHipError) as e:
