@@ -615,10 +615,26 @@ class Pipeline {
             HIP_TRY(launch_bucket_rise(d_freq, d_boff(), n_buckets, n, d_cnt, s));
             return UMI_OK;
         }
+        // With the LDS counting sort the segments' entries are prepared by its count kernel; the
+        // entry kernel keeps the other buckets' ranges (none at all for a call of deep positions:
+        // only the rises at bucket starts are left to count)
+        const bool fold = seg.blocks != nullptr;
+        if (fold) {
+            seg.prep_keys = d_keys;
+            seg.prep_nmask = d_nmask;
+            seg.prep_freq = d_freq;
+            seg.prep_thr = ctx->thr.as<int32_t>();
+            seg.prep_label = ctx->label.as<uint32_t>();
+            seg.prep_percentage = percentage;
+            seg.prep_counters = d_cnt;
+        }
+        bool other_ranges = false;
+        for (const RangeTask &r : pl.ranges) other_ranges = other_ranges || r.seg == SEG_NONE;
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, d_boff(), n_buckets, d_ranges,
                             (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
                             ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), nullptr, d_cnt,
-                            seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s));
+                            seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s, fold,
+                            !fold || other_ranges));
         return UMI_OK;
     }
 

@@ -201,12 +201,14 @@ constexpr int COL_TILE = 1024; // column keys staged in LDS per step
 
 // segs/bin_cnt (may be null): entries of ranges with a segment also count themselves into the
 // bins of their n_seg_parts parts
+// skip_seg: the ranges of segments are the count kernel's (SegArgs::prep_keys); entries_too false:
+// only the rises at bucket starts (every range is a segment's)
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
-                       uint32_t *bin_cnt, hipStream_t s);
+                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg = false, bool entries_too = true);
 
 // ---- segment index (umihip_seg.hip) ----
 struct SegArgs {
@@ -236,6 +238,15 @@ struct SegArgs {
     // directional batched path: parent array of the union-find (= label[]).  A pair permitted in both
     // directions is united where it is found instead of going through the edge list (null: listed)
     uint32_t *uf_parent;
+    // LDS path: the count kernel's blocks also do the entry kernel's work for their entries (filter
+    // key, threshold, label, contract check: prep_kernel then skips the segments' ranges) -- one
+    // launch and one pass over the keys less.  prep_keys null: prep_kernel has done it.
+    const uint64_t *prep_keys, *prep_nmask;
+    const int32_t *prep_freq;
+    int32_t *prep_thr;
+    uint32_t *prep_label;
+    float prep_percentage;
+    unsigned long long *prep_counters;
     int umi_len;
     uint32_t use_ckey; // 32-bit keys: the pair kernel compares the records' compare keys (every part of
                        // every segment leaves at most 10 bases outside its bins)
@@ -243,7 +254,7 @@ struct SegArgs {
 };
 // exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];
 // then every entry of a segment is copied to its position in each part's sub-bucket order
-hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *freq, bool key32,
+hipError_t launch_seg_build(const SegArgs &g, void *fkey, const int32_t *freq, bool key32,
                             unsigned long long *counters, hipStream_t s);
 constexpr uint32_t SEG_PRIV_CAP = 512; // = the LDS edge stage of a block
 // all pairs inside the sub-buckets: filter + exact check + edge emission (percentage: thresholds

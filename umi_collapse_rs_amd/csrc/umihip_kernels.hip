@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
                                                    uint32_t *__restrict__ lab,
                                                    unsigned long long *__restrict__ counters,
                                                    const SegDesc *__restrict__ segs, int n_seg_parts,
-                                                   uint32_t *__restrict__ bin_cnt)
+                                                   uint32_t *__restrict__ bin_cnt, int skip_seg)
 {
+    if (skip_seg && ranges && ranges[blockIdx.x].seg != SEG_NONE) return; // the count kernel's entries
     unsigned int bad = 0, rises = 0;
     // segment of this block's range (wave-uniform): its entries count themselves into the bins of
     // the segment's parts (the histogram of the counting sort, umihip_seg.hip)
@@ -2244,13 +2245,14 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
-                       uint32_t *bin_cnt, hipStream_t s)
+                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg, bool entries_too)
 {
     if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
-    prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
-                                                                     percentage, key32 ? 1 : 0, fkey, thr,
-                                                                     label, lab, counters, segs, n_seg_parts,
-                                                                     bin_cnt);
+    if (entries_too)
+        prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
+                                                                         percentage, key32 ? 1 : 0, fkey, thr,
+                                                                         label, lab, counters, segs, n_seg_parts,
+                                                                         bin_cnt, skip_seg ? 1 : 0);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
                                                                      ranges ? fused_max : 0u, n, counters);
     return hipGetLastError();

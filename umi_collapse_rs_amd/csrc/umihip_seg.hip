@@ -276,12 +276,48 @@ __device__ __forceinline__ void seg_block_histogram(const SegBlock &blk, const K
     __syncthreads();
 }
 
+// the filter key of an entry (umihip_kernels.hip's prep_kernel): 2 bits per base in 32 bits, or the
+// 3-bit key itself in 64, N (masked by n_bits) folded onto A
+__device__ __forceinline__ void store_filter_key(uint32_t *fkey, uint32_t i, uint64_t k3, int umi_len)
+{
+    uint32_t fk = 0;
+    for (int b = 0; b < umi_len; b++) fk |= (uint32_t)((k3 >> (3 * b)) & 3ull) << (2 * b);
+    fkey[i] = fk;
+}
+__device__ __forceinline__ void store_filter_key(uint64_t *fkey, uint32_t i, uint64_t k3, int) { fkey[i] = k3; }
+
 template <typename KeyT>
-__global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_count_lds_kernel(SegArgs g, const KeyT *__restrict__ fkey)
+__global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_count_lds_kernel(SegArgs g, KeyT *fkey)
 {
     extern __shared__ uint32_t hist[];
     const SegBlock blk = g.blocks[blockIdx.x];
     const SegDesc *__restrict__ sd = g.segs + blk.seg;
+    if (g.prep_keys) {
+        // the entry kernel's work for this block's entries (prep_kernel, umihip_kernels.hip): filter
+        // key, threshold (directional.rs:38), label, and the contract check -- freq >= 1, no N code
+        // without nmask, rises of freq (legal at a bucket's first entry only: bucket_rise_kernel
+        // counts those, the host wants the two counts equal)
+        unsigned int bad = 0, rises = 0;
+        for (uint32_t i = blk.start + threadIdx.x; i < blk.end; i += SEG_BLOCK_THREADS) {
+            const uint64_t key = g.prep_keys[i];
+            const uint64_t nm = g.prep_nmask ? g.prep_nmask[i] : 0ull;
+            const int32_t f = g.prep_freq[i];
+            g.prep_thr[i] = threshold_of(g.prep_percentage, f);
+            g.prep_label[i] = i;
+            const uint64_t k3 = key & ~nm;
+            store_filter_key(fkey, i, k3, g.umi_len);
+            bad += f < 1 ? 1u : 0u;
+            const uint64_t b2 = k3 & 0x4924924924924924ull;
+            bad += (b2 & ~((k3 << 1) | (k3 << 2))) != 0 ? 1u : 0u;
+            rises += (i > 0 && f > g.prep_freq[i - 1]) ? 1u : 0u;
+        }
+        if (__any(bad != 0u)) { // (rare: no reduction tree for it)
+            if (bad) atomicAdd(&g.prep_counters[CNT_ERROR], (unsigned long long)bad);
+        }
+        for (int off = 32; off > 0; off >>= 1) rises += __shfl_down(rises, off);
+        if ((threadIdx.x & 63) == 0 && rises) atomicAdd(&g.prep_counters[CNT_RISES], (unsigned long long)rises);
+        __syncthreads(); // the block's filter keys are read back below
+    }
     for (int j0 = 0; j0 < g.n_parts; j0 += (int)g.parts_per_pass) {
         const SegPass ps = seg_pass_of(sd, j0, g.n_parts, (int)g.parts_per_pass);
         seg_block_histogram(blk, fkey, ps, hist);
@@ -776,14 +812,14 @@ __global__ __launch_bounds__(64) void seg_edge_move_kernel(SegArgs g, const uint
 
 } // namespace
 
-hipError_t launch_seg_build(const SegArgs &g, const void *fkey, const int32_t *freq, bool key32,
+hipError_t launch_seg_build(const SegArgs &g, void *fkey, const int32_t *freq, bool key32,
                             unsigned long long *counters, hipStream_t s)
 {
     if (g.n_chunks == 0 || g.n_ranges == 0) return hipSuccess;
     const size_t lds = (size_t)g.lds_bins * g.parts_per_pass * sizeof(uint32_t);
     if (g.blocks) { // the histogram (else prep_kernel has counted the entries, one atomic each)
-        if (key32) seg_count_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint32_t *)fkey);
-        else seg_count_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint64_t *)fkey);
+        if (key32) seg_count_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (uint32_t *)fkey);
+        else seg_count_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (uint64_t *)fkey);
     }
     seg_scan_reduce_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g);
     seg_scan_spine_kernel<<<1, 1024, 0, s>>>(g, counters);
