@@ -1,7 +1,7 @@
 """Debug helper: replay one seed of tests/test_gpu_fuzz.py under several option sets and say
 where the output differs from the oracle (run on the GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
 import oracle as orc
 import umi_collapse_rs_amd as umi
