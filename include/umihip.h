@@ -118,7 +118,13 @@ const char *umi_last_error(void);
  * ranges -- and only the pairs inside a sub-bucket are evaluated; same result as the all-pairs
  * tile kernels, which take those buckets when it is 0 or k + 1 parts would be shorter than 3
  * bases; n_pairs_evaluated counts the pairs inside the sub-buckets), "seg_blocks" (one-wave
- * blocks of its pair kernel, 0 = 24 per CU), "two_phase" values: 0 plain label propagation,
+ * blocks of its pair kernel, 0 = 16 per CU), "seg_lds" (0/1, default 1: its counting sort through
+ * per-block LDS histograms; 0 = one atomic per entry), "seg_unite" (0/1, default 1: symmetric
+ * pairs are united where the pair kernel finds them; 0 = through the edge list), "seg_ckey"
+ * (0/1, default 1: the pair kernel compares 3-bit-per-base compare keys where the bases outside a
+ * bin fit 32 bits; 0 = the 2-bit filter keys), "table_pieces" (1..64, default 1: a bucket table of
+ * more than 4096 positions is walked, uploaded and handed to the fused kernel in this many
+ * pieces), "two_phase" values: 0 plain label propagation,
  * 1 components of the symmetric pairs by hook/jump rounds then the one-way pairs, 2 (default)
  * the components by union-find, "split_min" (multi-device contexts, see umi_ctx_create_multi).
  * Unknown name -> UMI_ERR_ARG. */
