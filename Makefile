@@ -7,7 +7,12 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unuse
 
 LIB := $(PKG)/libumihip.so
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_wide.o $(OBJDIR)/umihip_sort.o $(OBJDIR)/umihip_api.o
+OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_wide.o $(OBJDIR)/umihip_api.o
+# development build (make dev): the shipped sources plus the round-1 tile kernels, their key sort
+# and their options (-DUMIHIP_DEV), as libumihip_dev.so; the legacy cross-check tests load it
+DEVDIR := build/obj_dev
+DEVLIB := $(PKG)/libumihip_dev.so
+DEVOBJS := $(DEVDIR)/umihip_kernels.o $(DEVDIR)/umihip_seg.o $(DEVDIR)/umihip_collapse.o $(DEVDIR)/umihip_stage.o $(DEVDIR)/umihip_wide.o $(DEVDIR)/umihip_api.o $(DEVDIR)/umihip_legacy.o $(DEVDIR)/umihip_sort.o
 HDRS := $(CSRC)/umihip_internal.h $(CSRC)/umihip_device.h $(CSRC)/umihip_plan.hpp include/umihip.h
 CLI := $(PKG)/bin/umicollapse
 
@@ -24,6 +29,19 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 
 $(LIB): $(OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
+
+$(DEVDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(DEVDIR)
+	$(HIPCC) $(HIPFLAGS) -DUMIHIP_DEV -c -o $@ -x hip $<
+
+$(DEVDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(DEVDIR)
+	$(HIPCC) $(HIPFLAGS) -DUMIHIP_DEV -c -o $@ -x hip $<
+
+$(DEVLIB): $(DEVOBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVOBJS)
+
+dev: $(DEVLIB)
 
 $(CLI): $(LIB) $(PKG)/host/umicollapse_main.cpp $(PKG)/host/bam.hpp $(PKG)/host/bgzf.hpp include/umihip.h
 	mkdir -p $(PKG)/bin
@@ -45,8 +63,8 @@ cpptest: $(LIB) oracle tests/cpp/test_host.cpp $(PKG)/host/umi_collapse.hpp
 	    -L$(PKG) -lumihip -Loracle -lumi_oracle -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
 
 clean:
-	rm -f $(LIB) $(CLI)
+	rm -f $(LIB) $(DEVLIB) $(CLI)
 	rm -rf build
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle asm clean cpptest cli
+.PHONY: all dev oracle asm clean cpptest cli

@@ -88,46 +88,32 @@ int umi_partition_buckets(const uint64_t *bucket_off, uint64_t n_buckets, uint32
                           uint32_t *owner);
 /* Thread-local text of the last failure on this thread ("" if none). */
 const char *umi_last_error(void);
-/* Options: "profile" (0/1: record HIP events, fill ms_*), "edge_capacity"
- * (initial edge-list capacity, entries), "ovf_capacity" (initial capacity of the list of filter
- * hits that do not fit a block's on-chip queue; both lists grow by themselves), "small_max" (largest bucket handled by
- * the wave-per-chunk kernel), "bitslice" (0/1: use the bit-sliced tile kernel for
- * larger buckets, default 1; 0 = popcount tile kernel), "bs_col_chunk" (columns per
- * bit-sliced task), "fused_max" (largest bucket handled by the fused one-wave-per-bucket
- * kernel, 0..128, default 128), "fused_sliced" (0/1: that kernel's bit-sliced body, default 1;
- * it is used for k <= 3, the column-walking body otherwise), "bs_unit" (bases per counted unit of the bit-sliced filter:
- * 2 default, 1 = exact base count, 3 = k=1 and padded length divisible by 3 only, else 2),
- * "bs_sorted" (0/1, default 1: buckets of >= 32768 entries are sorted by filter key on the
- * device and the tile kernels reuse the evaluation of the high bases along runs of columns
- * that agree in them), "bs_tables" (0/1, default 1: with
- * bs_sorted and 32-bit keys, the two lowest 2-base units of a column are looked up in
- * per-lane register tables instead of being compared plane by plane, and a pair is not
- * evaluated further once its high bases differ in more than k units -- whole column tiles
- * and column runs at a time; n_pairs_evaluated counts what was walked), "bs_transposed"
- * (0/1, default 1: walk those items with the columns of a run across the lanes instead of the
- * register tables), "bs_tab_waves" (one-wave blocks of that walk; 0 = default, 128 per CU), "bs_tab_min_run" (that kernel only
- * for buckets where about this many sorted columns share their high bases, default 4; 0 =
- * every bucket of >= 32768 entries),
- * "two_phase" (0/1, default 1: directional collapse as connected components of the symmetric
- * pairs followed by propagation along the one-way pairs; 0 = plain label propagation over all
- * pairs, one hop per round),
- * "prune" (0 default / 1: sort large buckets by key and skip tile tasks whose key ranges
- * cannot hold a pair within k -- same result, fewer comparisons executed),
- * "seg_index" (0/1, default 1: buckets of at least "seg_min" entries, default 512, are cut into
- * n-gram sub-buckets on the device -- two UMIs within k substitutions agree on one of k+1 base
- * ranges -- and only the pairs inside a sub-bucket are evaluated; same result as the all-pairs
- * tile kernels, which take those buckets when it is 0 or k + 1 parts would be shorter than 3
- * bases; n_pairs_evaluated counts the pairs inside the sub-buckets), "seg_blocks" (one-wave
- * blocks of its pair kernel, 0 = 16 per CU), "seg_lds" (0/1, default 1: its counting sort through
- * per-block LDS histograms; 0 = one atomic per entry), "seg_unite" (0/1, default 1: symmetric
- * pairs are united where the pair kernel finds them; 0 = through the edge list), "seg_ckey"
- * (0/1, default 1: the pair kernel compares 3-bit-per-base compare keys where the bases outside a
- * bin fit 32 bits; 0 = the 2-bit filter keys), "table_pieces" (1..64, default 1: a bucket table of
- * more than 4096 positions is walked, uploaded and handed to the fused kernel in this many
- * pieces), "two_phase" values: 0 plain label propagation,
- * 1 components of the symmetric pairs by hook/jump rounds then the one-way pairs, 2 (default)
- * the components by union-find, "split_min" (multi-device contexts, see umi_ctx_create_multi).
- * Unknown name -> UMI_ERR_ARG. */
+/* Options (none of them changes a result; unknown name -> UMI_ERR_ARG):
+ *   "profile"        0/1: record HIP events, fill the ms_* fields of umi_stats
+ *   "edge_capacity"  initial capacity of the permitted-pair list, entries (it grows by itself)
+ *   "fused_max"      0..128 (default 128): largest bucket the fused one-wave-per-bucket kernel takes
+ *   "fused_sliced"   0/1 (default 1): that kernel's bit-sliced body for k <= 3 (0: columns one by one)
+ *   "small_max"      (default 1024) largest bucket taken as 64-row popcount chunks; above, 2048-row tiles
+ *   "seg_index"      0/1 (default 1): buckets of at least "seg_min" entries (default 512) are cut into
+ *                    n-gram sub-buckets on the device -- two UMIs within k substitutions agree on one of
+ *                    k + 1 base ranges -- and only the pairs inside a sub-bucket are evaluated; same
+ *                    result as the all-pairs popcount kernels, which take those buckets when it is 0 or
+ *                    when k + 1 parts would be shorter than 3 bases (the parity suite's cross-check);
+ *                    n_pairs_evaluated counts the pairs inside the sub-buckets
+ *   "seg_min"        2..2^31, see above
+ *   "seg_blocks"     one-wave blocks of the segment index's pair kernel (0 = 16 per CU)
+ *   "seg_lds"        0/1 (default 1): its counting sort through per-block LDS histograms (0: one atomic
+ *                    per entry)
+ *   "seg_unite"      0/1 (default 1): symmetric pairs united where the pair kernel finds them (0: through
+ *                    the list)
+ *   "seg_ckey"       0/1 (default 1): the pair kernel compares 3-bit-per-base compare keys where the bases
+ *                    outside a bin fit 32 bits (0: the 2-bit filter keys)
+ *   "table_pieces"   1..64 (default 1): a bucket table of more than 4096 positions is walked, uploaded
+ *                    and handed to the fused kernel in this many pieces
+ *   "split_min"      multi-device contexts, see umi_ctx_create_multi
+ * The round-1 tile kernels (bit-sliced masks, key-sorted scan + item walk, range pruning, hook/jump
+ * collapse) and their options ("bitslice", "bs_*", "prune", "two_phase", "ovf_capacity") exist in the
+ * development build only (make dev: libumihip_dev.so, -DUMIHIP_DEV), as cross-checks. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
 /* 1 if this library was built with device code for gfx950 (always), for loaders */
 int umi_abi_version(void);

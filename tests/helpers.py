@@ -97,3 +97,28 @@ def canonical(umis, freq):
     """Stable freq-descending order (the rank order the batched ABI expects)."""
     order = sorted(range(len(umis)), key=lambda i: (-freq[i], i))
     return [umis[i] for i in order], [freq[i] for i in order], order
+
+
+# ---- shipped library vs development build ---------------------------------------------------------
+# The round-1 tile kernels and their options live in libumihip_dev.so only (make dev, -DUMIHIP_DEV).
+# Run the legacy cross-checks with UMIHIP_LIB=<repo>/umi_collapse_rs_amd/libumihip_dev.so; under the
+# shipped library they are skipped and option sets that name a legacy option are left out.
+LEGACY_OPTS = {"prune", "bs_unit", "bs_sorted", "bs_tables", "two_phase", "bs_col_chunk", "bs_tab_min_run",
+               "bs_transposed", "bs_tab_waves", "bitslice", "ovf_capacity"}
+
+
+def is_dev_build():
+    import os
+    from umi_collapse_rs_amd import _lib
+    return os.path.basename(_lib.LIB_PATH) == "libumihip_dev.so"
+
+
+def usable(opts):
+    """Can this option set be applied to the library under test?"""
+    return is_dev_build() or not (set(opts) & LEGACY_OPTS)
+
+
+def legacy_mark():
+    import pytest
+    return pytest.mark.skipif(not is_dev_build(), reason="round-1 tile kernels: development build only "
+                                                          "(UMIHIP_LIB=.../libumihip_dev.so)")

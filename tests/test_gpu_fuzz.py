@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
+from helpers import usable
 
 pytestmark = pytest.mark.gpu
 ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -54,7 +55,9 @@ def test_fuzz_against_oracle(seed):
     fr, off = np.array(fr, np.int32), np.array(off, np.uint64)
     okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
     for opts in ({}, {"prune": 1}, {"bitslice": 0, "fused_max": 0}, {"bs_unit": 1, "small_max": 200, "seg_index": 0},
-                 {"seg_index": 0}, {"seg_min": 129, "two_phase": 1}):
+                 {"seg_index": 0}, {"seg_min": 129, "two_phase": 1}, {"seg_min": 129, "fused_max": 0}):
+        if not usable(opts):
+            continue
         ctx = umi.Context(0)
         try:
             for name, v in opts.items():
@@ -89,6 +92,8 @@ def test_fuzz_wide_buckets(seed):
     fr, off = np.array(fr, np.int32), np.array(off, np.uint64)
     okept, oroot, _ = orc.dedup_batch(keys, nm, fr, off, L, k, p, algo, amf)
     for opts in ({}, {"seg_index": 0}, {"seg_index": 0, "bs_tables": 0}, {"prune": 1}, {"two_phase": 1}):
+        if not usable(opts):
+            continue
         ctx = umi.Context(0)
         try:
             for name, v in opts.items():

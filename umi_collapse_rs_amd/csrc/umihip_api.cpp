@@ -127,7 +127,12 @@ struct umi_ctx {
     uint64_t edge_capacity = 1u << 20;
     uint64_t ovf_capacity = 1u << 18; // filter hits beyond the blocks' LDS queues (grows like the edge list)
     uint32_t small_max = 1024;
-    bool use_bitslice = true;
+#ifdef UMIHIP_DEV
+    static constexpr bool LEGACY_DEFAULT = true;
+#else
+    static constexpr bool LEGACY_DEFAULT = false; // the round-1 tile kernels are not in this build
+#endif
+    bool use_bitslice = LEGACY_DEFAULT;
     uint32_t bs_col_chunk = BS_COL_CHUNK;
     uint32_t bs_tab_min_run = 4; // table variant only where a run of equal high bases is about this long
     bool bs_transposed = true; // table variant: walk items with the columns of a run across the lanes
@@ -136,8 +141,8 @@ struct umi_ctx {
     uint32_t fused_max = FUSED_MAX;
     bool fused_sliced = true;
     int bs_unit = 2;
-    bool bs_sorted = true; // sort large buckets by key and reuse prefix state along column runs
-    bool bs_tables = true; // ... and look the low units up in per-lane register tables (32-bit keys)
+    bool bs_sorted = LEGACY_DEFAULT; // sort large buckets by key and reuse prefix state along column runs
+    bool bs_tables = LEGACY_DEFAULT; // ... and look the low units up in per-lane register tables (32-bit keys)
     int two_phase = 2; // directional collapse: 0 plain label propagation; 1 components of the symmetric
                        // pairs by hook/jump rounds, then the DAG; 2 the components by union-find
     bool seg_index = true;   // large buckets through the n-gram partition (umihip_seg.hip)
@@ -150,7 +155,6 @@ struct umi_ctx {
     bool seg_unite = true;   // its pair kernel unites symmetric pairs on the spot (batched directional path)
     bool seg_lds = true;     // counting sort of the partition through per-block LDS histograms (where
                              // every part has at most SEG_LDS_BINS bins), else one atomic per entry
-    uint32_t seg_dbg = 0;
     int seg_occ[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
     uint32_t seg_blocks = 0; // one-wave blocks of its pair kernel (0: all resident at once -- 24 per CU by
                              // registers, 28 by LDS with the compare keys' leaner loop)
@@ -231,21 +235,26 @@ int directional_labels(umi_ctx *ctx, const uint2 *d_edges, unsigned long long *d
 {
     int rc;
     uint32_t *d_label = ctx->label.as<uint32_t>();
+#ifdef UMIHIP_DEV
     if (!ctx->two_phase)
         return run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
             return launch_prop_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
         }, rounds);
+#endif
     if ((rc = ctx->lab.reserve((size_t)n * 4))) return rc;
     uint32_t *d_lab = ctx->lab.as<uint32_t>();
-    if (ctx->two_phase == 2) {
-        HIP_TRY(launch_uf_components(d_edges, d_cnt, edge_cap, d_label, d_lab, n, (uint32_t)n_edges, s));
-        rounds++;
-    } else {
+#ifdef UMIHIP_DEV
+    if (ctx->two_phase != 2) {
         HIP_TRY(launch_iota(d_lab, n, s));
         if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
                  return launch_cc_round(d_edges, d_cnt, edge_cap, d_label, n, d_changed, r, (uint32_t)n_edges, s);
              }, rounds, 6))) // a giant component of 10^6 entries settles in 5
             return rc;
+    } else
+#endif
+    {
+        HIP_TRY(launch_uf_components(d_edges, d_cnt, edge_cap, d_label, d_lab, n, (uint32_t)n_edges, s));
+        rounds++;
     }
     if ((rc = run_rounds(ctx, s, [&](uint32_t *d_changed, int r) {
              return launch_dag_round(d_edges, d_cnt, edge_cap, d_label, d_lab, n, d_changed, r,
@@ -334,7 +343,7 @@ class Pipeline {
     uint64_t seg_tasks_made = 0;
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
-    const uint32_t *bs_perm = nullptr;
+    [[maybe_unused]] const uint32_t *bs_perm = nullptr;
     // device tables of the plan (inside ctx->plan_tables)
     const RangeTask *d_ranges = nullptr;
     const SegDesc *d_segs = nullptr;
@@ -346,7 +355,11 @@ class Pipeline {
     // The bit-sliced tile kernels of the earlier versions (options bs_sorted / bs_tables / prune,
     // k > the segment index's reach, seg_index = 0) keep their own overflow list, which the host
     // has to look at between the pair stage and the collapse.
+#ifdef UMIHIP_DEV
     bool legacy_tiles() const { return pl.n_bs() || !pl.tab_rows.empty(); }
+#else
+    bool legacy_tiles() const { return false; }
+#endif
     // Everything of a call enqueued back to back, one synchronisation at the end: the batched
     // directional path (and the reference's adjacency, which needs no pairs) without those tiles.
     bool one_sync() const
@@ -371,6 +384,7 @@ class Pipeline {
         if (!plan_first) plan_host();
         if ((rc = upload_plan())) return rc;
         if ((rc = prep_stage())) return rc;
+#ifdef UMIHIP_DEV
         if (prune) {
             if ((rc = prune_stage())) return rc;
         } else {
@@ -380,6 +394,7 @@ class Pipeline {
             gen_bs_tasks(pl, umi_len, ctx->bs_col_chunk, k, nullptr, key32);
             for (auto &v : pl.bs_tasks) keep_my_share(v);
         }
+#endif
         if (need_pairs && pl.seg_parts)
             HIP_TRY(launch_seg_build(seg, ctx->fkey.p, d_freq, key32, d_cnt, s));
         if ((rc = upload_bitsliced())) return rc;
@@ -518,7 +533,6 @@ class Pipeline {
             seg.sub_rec = ctx->seg_sub_rec.p;
             seg.ranges = d_ranges;
             seg.n_ranges = (uint32_t)pl.ranges.size();
-            seg.dbg = ctx->seg_dbg;
             seg.umi_len = umi_len;
             seg.use_ckey = key32 && ctx->seg_ckey && pl.seg_max_rest <= 10 ? 1u : 0u;
             if (ctx->seg_lds && pl.seg_max_bins <= SEG_LDS_BINS && !pl.seg_blocks.empty()) {
@@ -638,6 +652,7 @@ class Pipeline {
         return UMI_OK;
     }
 
+#ifdef UMIHIP_DEV
     // optional: sort every large bucket by filter key, read back the keys at the tile
     // boundaries, keep only the tile tasks whose key ranges can still hold a pair within k
     int prune_stage()
@@ -719,12 +734,15 @@ class Pipeline {
         return UMI_OK;
     }
 
+#endif // UMIHIP_DEV
+
     // bit-sliced tile tasks + bit planes of the large buckets the segment index does not take
     int upload_bitsliced()
     {
         n_tasks = pl.small_tasks.size() + pl.big_tasks.size() + pl.n_bs() + pl.tab_rows.size() +
                   (pl.seg_parts ? 1 : 0);
         if (need_pairs) st.n_pairs_evaluated = pl.n_pairs_eval;
+#ifdef UMIHIP_DEV
         if (need_pairs && legacy_tiles()) {
             int rc;
             if (pl.tab_items_max > 0x7FFFFFF0ull / sizeof(TabItem))
@@ -756,6 +774,7 @@ class Pipeline {
                                         (uint32_t)pl.plane_tasks.size(), ctx->planes.as<uint32_t>(),
                                         umi_len, s));
         }
+#endif
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[1], s));
         return UMI_OK;
     }
@@ -827,6 +846,7 @@ class Pipeline {
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             st.n_pair_launches += 1;
         }
+#ifdef UMIHIP_DEV
         PairArgs b = a; // bit-sliced tiles are cut from the key-sorted arrays
         b.fkey = bs_fkey;
         b.perm = bs_perm;
@@ -845,6 +865,7 @@ class Pipeline {
             HIP_TRY(launch_bs_pairs(w, (uint32_t)pl.bs_tasks[li].size(), li != 0, key32, umi_len,
                                     ctx->bs_unit, li == 2 ? 3 : (li == 3 ? 4 : 0), s));
         }
+#endif
         if (wide()) { // every bucket as 64-row chunks against its later entries
             HIP_TRY(launch_wide_pairs(a, (uint32_t)pl.small_tasks.size(), n_words, s));
             st.n_pair_launches += pl.small_tasks.empty() ? 0 : 1;
@@ -895,7 +916,9 @@ class Pipeline {
             if (n_ovf > ovf_cap) {
                 ctx->ovf_capacity = n_ovf + n_ovf / 8 + 1024;
                 redo = true;
-            } else if (n_ovf) {
+            }
+#ifdef UMIHIP_DEV
+            else if (n_ovf) {
                 PairArgs b;
                 memset(&b, 0, sizeof(b));
                 b.keys = d_keys;
@@ -918,6 +941,7 @@ class Pipeline {
                 st.n_pair_launches += 1;
                 if ((rc = sync_counters())) return rc;
             }
+#endif
             if (prof && !redo) HIP_TRY(hipEventRecord(ctx->ev[2], s));
             note_pair_counters();
             if (pl.seg_parts && seg_tasks_made > seg.task_cap)
@@ -1559,6 +1583,7 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "edge_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "edge_capacity must be >= 1");
         ctx->edge_capacity = (uint64_t)value;
+#ifdef UMIHIP_DEV
     } else if (!strcmp(name, "prune")) {
         ctx->prune = value != 0;
     } else if (!strcmp(name, "bs_unit")) {
@@ -1571,30 +1596,6 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "two_phase")) {
         if (value < 0 || value > 2) return fail(UMI_ERR_ARG, "two_phase must be 0, 1 or 2");
         ctx->two_phase = (int)value;
-    } else if (!strcmp(name, "seg_index")) {
-        ctx->seg_index = value != 0;
-    } else if (!strcmp(name, "table_pieces")) {
-        if (value < 1 || value > 64) return fail(UMI_ERR_ARG, "table_pieces must be in 1..64");
-        ctx->table_pieces = (uint32_t)value;
-    } else if (!strcmp(name, "seg_ckey")) {
-        ctx->seg_ckey = value != 0;
-    } else if (!strcmp(name, "seg_unite")) {
-        ctx->seg_unite = value != 0;
-    } else if (!strcmp(name, "seg_lds")) {
-        ctx->seg_lds = value != 0;
-    } else if (!strcmp(name, "seg_dbg")) {
-        ctx->seg_dbg = (uint32_t)value;
-    } else if (!strcmp(name, "seg_blocks")) {
-        if (value < 0 || value > (1 << 22)) return fail(UMI_ERR_ARG, "seg_blocks must be in 0..2^22");
-        ctx->seg_blocks = (uint32_t)value;
-    } else if (!strcmp(name, "seg_min")) {
-        if (value < 2 || value > (1ll << 31)) return fail(UMI_ERR_ARG, "seg_min must be in 2..2^31");
-        ctx->seg_min = (uint32_t)value;
-    } else if (!strcmp(name, "fused_sliced")) {
-        ctx->fused_sliced = value != 0;
-    } else if (!strcmp(name, "fused_max")) {
-        if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
-        ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);
     } else if (!strcmp(name, "bs_col_chunk")) {
         if (value < BS_COL_TILE || value > (1 << 24) || value % BS_COL_TILE)
             return fail(UMI_ERR_ARG, "bs_col_chunk must be a multiple of %d in %d..%d", BS_COL_TILE,
@@ -1613,6 +1614,29 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "ovf_capacity")) {
         if (value < 1) return fail(UMI_ERR_ARG, "ovf_capacity must be >= 1");
         ctx->ovf_capacity = (uint64_t)value;
+#endif
+    } else if (!strcmp(name, "seg_index")) {
+        ctx->seg_index = value != 0;
+    } else if (!strcmp(name, "table_pieces")) {
+        if (value < 1 || value > 64) return fail(UMI_ERR_ARG, "table_pieces must be in 1..64");
+        ctx->table_pieces = (uint32_t)value;
+    } else if (!strcmp(name, "seg_ckey")) {
+        ctx->seg_ckey = value != 0;
+    } else if (!strcmp(name, "seg_unite")) {
+        ctx->seg_unite = value != 0;
+    } else if (!strcmp(name, "seg_lds")) {
+        ctx->seg_lds = value != 0;
+    } else if (!strcmp(name, "seg_blocks")) {
+        if (value < 0 || value > (1 << 22)) return fail(UMI_ERR_ARG, "seg_blocks must be in 0..2^22");
+        ctx->seg_blocks = (uint32_t)value;
+    } else if (!strcmp(name, "seg_min")) {
+        if (value < 2 || value > (1ll << 31)) return fail(UMI_ERR_ARG, "seg_min must be in 2..2^31");
+        ctx->seg_min = (uint32_t)value;
+    } else if (!strcmp(name, "fused_sliced")) {
+        ctx->fused_sliced = value != 0;
+    } else if (!strcmp(name, "fused_max")) {
+        if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
+        ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);
     } else if (!strcmp(name, "small_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "small_max must be >= 0");
         ctx->small_max = (uint32_t)std::min<int64_t>(value, 1 << 30);
@@ -1651,8 +1675,13 @@ int umi_partition_buckets(const uint64_t *bucket_off, uint64_t n_buckets, uint32
 {
     if (!bucket_off || (!owner && n_buckets)) return fail(UMI_ERR_ARG, "bucket_off/owner is NULL");
     if (n_ranks < 1) return fail(UMI_ERR_ARG, "n_ranks must be >= 1");
-    for (uint64_t b = 0; b < n_buckets; b++)
+    for (uint64_t b = 0; b < n_buckets; b++) {
         if (bucket_off[b + 1] < bucket_off[b]) return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
+        // (the cost n_b^2 + n_b is kept in 64 bits; the batched calls take no larger bucket either)
+        if (bucket_off[b + 1] - bucket_off[b] >= 0x7FFFFFF0ull)
+            return fail(UMI_ERR_ARG, "bucket %llu holds %llu entries: beyond the 31-bit index space of one call",
+                        (unsigned long long)b, (unsigned long long)(bucket_off[b + 1] - bucket_off[b]));
+    }
     std::vector<uint32_t> o;
     partition_buckets_lpt(bucket_off, n_buckets, n_ranks, o);
     for (uint64_t b = 0; b < n_buckets; b++) owner[b] = o[b];
@@ -1760,7 +1789,7 @@ int umi_dedup_batch_wide_device(umi_ctx *ctx, const uint64_t *d_keys, const uint
     }
     return run_pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY, adj_max_freq, d_kept, d_root,
-                        hip_stream ? (hipStream_t)hip_stream : ctx->own_stream, stats, nullptr, n_words);
+                        (hipStream_t)hip_stream, stats, nullptr, n_words);
 }
 
 int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
@@ -1821,7 +1850,7 @@ int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads)))) return rc;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t s = (hipStream_t)hip_stream; // (NULL = the default stream, as in every device-pointer call)
     const int r = stage_reads_on_device(ctx->stage_ws.p, d_align_key, align_key_bits, d_umi_ascii, d_score,
                                         (uint32_t)n_reads, umi_len, merge, d_keys, d_nmask, d_freq, d_rep, d_bucket_off,
                                         n_entries, n_buckets, ctx->h_counters, s);

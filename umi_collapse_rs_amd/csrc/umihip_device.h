@@ -13,6 +13,11 @@ namespace {
 
 constexpr int CHECK_BLOCK = 32; // columns between two "any hit?" checks
 
+// v_bitop3_b32: any boolean of three words in one instruction; tt = the truth table over
+// TT_A / TT_B / TT_C (the columns of the first, second, third operand)
+#define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+constexpr unsigned TT_A = 0xF0, TT_B = 0xCC, TT_C = 0xAA;
+
 __device__ __forceinline__ int popc(uint32_t x) { return __builtin_popcount(x); }
 __device__ __forceinline__ int popc(uint64_t x) { return __builtin_popcountll(x); }
 

@@ -250,7 +250,6 @@ struct SegArgs {
     int umi_len;
     uint32_t use_ckey; // 32-bit keys: the pair kernel compares the records' compare keys (every part of
                        // every segment leaves at most 10 bases outside its bins)
-    uint32_t dbg; // tuning experiments only (ctx option seg_dbg): 1 drop the queued hits, 2 skip the column loop
 };
 // exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];
 // then every entry of a segment is copied to its position in each part's sub-bucket order

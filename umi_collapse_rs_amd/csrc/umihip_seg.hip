@@ -586,7 +586,6 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
     // path) or staged as well.
     auto drain = [&]() {
         __builtin_amdgcn_wave_barrier();
-        if (g.dbg & 1u) nq = 0;
         for (uint32_t q0 = 0; q0 < nq; q0 += 64 * ILP) {
             Rec ra[ILP], cb[ILP];
             bool live[ILP];
@@ -624,7 +623,7 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                     dist = filter_key_distance(ra[s].key, cb[s].key);
                 }
                 n_cand++;
-                if (dist > a.k || (g.dbg & 4u)) continue;
+                if (dist > a.k) continue;
                 if (a.mode == MODE_NEIGHBOURS) {
                     emit_edge(&stage, a.edges, a.edge_dist, a.counters, a.edge_cap, gi, gj, dist, true);
                     continue;
@@ -715,7 +714,7 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                 const uint32_t cn_pos = c0 + 64u + (uint32_t)lane;
                 KeyT kn = pad_col<KeyT>();
                 if (c0 + 64u < col1 && cn_pos < end) kn = loop_key<CK>(sub[cn_pos]);
-                const uint32_t nc = (g.dbg & 2u) ? 0u : min(64u, end - c0);
+                const uint32_t nc = min(64u, end - c0);
                 uint32_t hlo = 0, hhi = 0; // bit j: this lane's row is within k of column j of the tile
                 hlo = columns32<CK, 0>(x, ky, a.k, lim2);
                 if (nc > 32) hhi = columns32<CK, 32>(x, ky, a.k, lim2);

@@ -132,8 +132,7 @@ void usage()
               "      --umi_sep <BYTE>     Separator byte value between UMI and read name [default: 95]\n"
               "      --algo <ALGO>        adj or dir [default: dir]\n"
               "      --merge <MERGE>      any, avgqual or mapqual [default: mapqual in bam mode]\n"
-              "      --data <DATA>        every value gives Naive's result (as in the reference);\n"
-              "                           naive = plain all-pairs, others = + exact range pruning\n"
+              "      --data <DATA>        accepted; every value gives Naive's result (as in the reference)\n"
               "      --keep-unmapped      Keep unmapped reads\n"
               "      --paired             Paired-end mode: template length joins the alignment key,\n"
               "                           second mates follow their surviving first mates\n"
@@ -145,6 +144,15 @@ void usage()
               "      --stage <WHERE>      gpu, host or auto: where reads are merged per (position, UMI) [default: auto]\n"
               "      --device <ID>        GPU to use [default: 0]\n"
               "      --devices <ID,..>    several GPUs of the node: alignment positions are sharded over them");
+}
+
+// a GPU id: decimal digits only (atoi would take "x" for device 0)
+int device_id(const char *text)
+{
+    char *end = nullptr;
+    const long v = std::strtol(text, &end, 10);
+    if (end == text || *end != '\0' || v < 0 || v > 1023) die(std::string("not a GPU id: '") + text + "'");
+    return (int)v;
 }
 
 Cli parse(int argc, char **argv)
@@ -176,14 +184,14 @@ Cli parse(int argc, char **argv)
         else if (a == "--dump-staging") c.dump_staging = need(i);
         else if (a == "--passthrough") c.passthrough = true;
         else if (a == "--stage") c.stage = need(i);
-        else if (a == "--device") c.devices.assign(1, std::atoi(need(i)));
+        else if (a == "--device") c.devices.assign(1, device_id(need(i)));
         else if (a == "--devices") { // the GPUs of the node the position buckets are sharded over
             c.devices.clear();
             std::string list = need(i);
             for (size_t p = 0; p <= list.size();) {
                 const size_t q = std::min(list.find(',', p), list.size());
                 if (q == p) die("--devices wants a comma separated list of GPU ids");
-                c.devices.push_back(std::atoi(list.substr(p, q - p).c_str()));
+                c.devices.push_back(device_id(list.substr(p, q - p).c_str()));
                 p = q + 1;
             }
         }
@@ -573,10 +581,7 @@ int main(int argc, char **argv)
         if (!args.passthrough && n) {
             need_ctx();
             // The reference accepts every --data value and always runs Naive
-            // (deduplicate_sam.rs:210-213), so the result is the same for all of them.  Here
-            // "naive" is the plain all-pairs tile walk; any other value (the default is
-            // "ngrambktree") adds the exact range pruning of key-sorted tiles on deep positions.
-            if (lib.ctx_set_option(ctx, "prune", args.data != "naive") != UMI_OK) die(lib.last_error());
+            // (deduplicate_sam.rs:210-213): the result -- and here the path -- is the same for all of them.
             t_gpu0 = now_s();
             if (lib.dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
                                 (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
