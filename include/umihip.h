@@ -64,7 +64,14 @@ typedef struct umi_stats {
     float ms_pairs;
     float ms_collapse;
     float ms_finalize;
+    /* (ABI version 2) with "profile": HIP-event time of the kernel that does the call's pair work, alone
+     * -- what a roofline of the call is quoted on -- and which one it was */
+    float ms_kernel;
+    uint32_t kernel_id; /* UMI_KERNEL_* */
 } umi_stats;
+#define UMI_KERNEL_NONE 0
+#define UMI_KERNEL_FUSED 1     /* small_bucket_kernel: one wave per position of <= 128 UMIs */
+#define UMI_KERNEL_SEG_PAIRS 2 /* seg_pair_kernel: all pairs inside the n-gram sub-buckets of deep positions */
 
 /* ---- context ----------------------------------------------------------- */
 int umi_ctx_create(int device_id, umi_ctx **out);
@@ -115,7 +122,8 @@ const char *umi_last_error(void);
  * collapse) and their options ("bitslice", "bs_*", "prune", "two_phase", "ovf_capacity") exist in the
  * development build only (make dev: libumihip_dev.so, -DUMIHIP_DEV), as cross-checks. */
 int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value);
-/* 1 if this library was built with device code for gfx950 (always), for loaders */
+/* Version of this header the library was built from (umi_stats grew in 2), for loaders */
+#define UMI_ABI_VERSION 2
 int umi_abi_version(void);
 
 /* ---- staging helper: src/utils/mod.rs:63-83 (to_bitset) ---------------- */

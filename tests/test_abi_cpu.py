@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(L, name) is not None
-    assert umi.load().umi_abi_version() == 1
+    assert umi.load().umi_abi_version() == 2
 
 
 def test_encode_matches_oracle_and_kat(kat):

@@ -202,3 +202,63 @@ def test_one_process_per_gpu_driver_on_its_hip_path():
     expect = orc.dedup_batch(keys, None, fr, off, 12, 1)[0]
     for r in range(2):
         assert (np.frombuffer(got[r], np.uint8) == expect).all()
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from umi_collapse_rs_amd.sharded import ShardedDedup
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    keys, nm, fr, off = _mixed_batch(777)
+    sd = ShardedDedup(dist, umi_len=12, k=1)
+    kept = sd.run(keys, None, fr, off)  # dedup_batch_device + pack_mask_device + RCCL all_gather_into_tensor
+    q.put(kept.tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_of_the_sharded_driver_with_one_rank():
+    """The "nccl" (= RCCL) branch of ShardedDedup -- device-resident shard, mask packed to bits on the
+    device, all_gather_into_tensor on device buffers -- with a communicator of ONE rank: all a 1-GPU
+    box can form.  It shows that the collective is issued on buffers RCCL accepts and that the result
+    comes back intact; what more ranks do over xGMI is the driver's 8-GPU run to observe (the
+    2-rank rehearsal above uses gloo on the same code path up to the collective)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    keys, nm, fr, off = _mixed_batch(777)
+    expect = orc.dedup_batch(keys, None, fr, off, 12, 1)[0]
+    assert (np.frombuffer(got, np.uint8) == expect).all()
+
+
+def test_bench_rehearsal_two_ranks_over_gloo_and_one_rank_over_rccl(tmp_path):
+    """bench.py's N > 1 path end to end on this box: 2 ranks over gloo (config 4's share shrunk,
+    config 5 and config 2 blocks behind it), and the same code with --force-collective over a
+    one-rank RCCL communicator: the line parses and carries the blocks the driver's 8-GPU run will."""
+    import json
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "3", "--warmup", "1", "--reads", "500000", "--also", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["baseline_config"] == "4" and line["scaling"] == "weak"
+    assert line["configs"]["2"]["ms_per_step"] > 0 and line["value"] > 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--config", "4", "--reads", "500000", "--no-extras", "--force-collective"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["collective"] == "nccl" and line["value"] > 0

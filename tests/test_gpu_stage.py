@@ -94,3 +94,39 @@ def test_staging_rejects_what_the_reference_panics_on(ctx):
         ctx.stage_reads(np.zeros(2, np.uint64), umis, None, 12)
     st = ctx.stage_reads(np.zeros(0, np.uint64), np.zeros(0, np.uint8), None, 12)  # no reads at all
     assert len(st["keys"]) == 0 and st["bucket_off"].tolist() == [0]
+
+
+def test_device_form_runs_on_the_callers_stream_default_stream_included(ctx):
+    """umi_stage_reads_device with hip_stream = NULL works on the default stream like every other
+    device-pointer call: inputs filled by kernels enqueued on the default stream just before the call,
+    with no synchronisation in between, are what it stages (a non-blocking private stream would not
+    be ordered behind them).  A long fill chain makes the race wide: the inputs only reach their final
+    values after ~100 passes over 4 M reads."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, L = 4_000_000, 12
+    pos, umi, score = make_reads(rng, n, 5000, L, 6)
+    dev = torch.device("cuda", 0)
+    h_key = torch.from_numpy(pos.astype(np.int64))
+    d_key = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_umi = torch.from_numpy(umi.copy()).to(dev)
+    d_score = torch.from_numpy(score).to(dev)
+    final = h_key.to(dev)
+    outs = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(3)]  # keys, nmask, rep
+    d_freq = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_stream().cuda_stream == 0
+    for i in range(100):  # on the default stream, nothing waited for
+        d_key.add_(1)
+    d_key.copy_(final)
+    ne, nb = ctx.stage_reads_device(d_key.data_ptr(), d_umi.data_ptr(), d_score.data_ptr(), n, L,
+                                    outs[0].data_ptr(), outs[1].data_ptr(), d_freq.data_ptr(), outs[2].data_ptr(),
+                                    d_off.data_ptr(), merge=1, align_key_bits=64, stream=0)
+    torch.cuda.synchronize()
+    want = orc.stage_reads(dense_ids(pos), umi, score, L, 1)
+    assert ne == len(want["keys"]) and nb == len(want["bucket_off"]) - 1
+    assert (outs[0][:ne].cpu().numpy().view(np.uint64) == want["keys"]).all()
+    assert (d_freq[:ne].cpu().numpy() == want["freq"]).all()
+    assert (outs[2][:ne].cpu().numpy().view(np.uint64) == want["rep"]).all()
+    assert (d_off[:nb + 1].cpu().numpy().view(np.uint64) == want["bucket_off"]).all()

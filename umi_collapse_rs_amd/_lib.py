@@ -27,7 +27,7 @@ class Stats(C.Structure):
                 ("n_edges", C.c_uint64), ("n_rounds", C.c_uint32),
                 ("n_pair_launches", C.c_uint32), ("ms_total", C.c_float),
                 ("ms_prep", C.c_float), ("ms_pairs", C.c_float), ("ms_collapse", C.c_float),
-                ("ms_finalize", C.c_float)]
+                ("ms_finalize", C.c_float), ("ms_kernel", C.c_float), ("kernel_id", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

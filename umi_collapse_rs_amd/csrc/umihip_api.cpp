@@ -4,6 +4,7 @@
 #include "../../include/umihip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -179,7 +180,8 @@ struct umi_ctx {
     unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES)
     uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
     uint32_t *d_changed() const { return (uint32_t *)(counters.as<unsigned long long>() + CNT_COUNT); }
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int N_EVENTS = 10;
+    hipEvent_t ev[N_EVENTS] = {};
 };
 
 namespace {
@@ -334,7 +336,7 @@ class Pipeline {
     const uint32_t part, n_parts; // n_parts > 1: evaluate only every n_parts-th tile task, stop
                                   // after the pair kernels (multi-GPU split of one call's pairs)
     uint64_t task_counter = 0;    // running index over all tile tasks, for that split
-    bool prune = false, drained = false, fused_ran = false;
+    bool prune = false, drained = false, fused_ran = false, seg_timed = false;
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
@@ -843,7 +845,11 @@ class Pipeline {
             seg.priv_cnt = ctx->seg_priv_cnt.as<uint32_t>();
             seg.uf_parent = one_sync() && ctx->seg_unite ? ctx->label.as<uint32_t>() : nullptr;
 
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[7], s));
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
+            if (prof) HIP_TRY(hipEventRecord(ctx->ev[8], s));
+            seg_timed = true;
+            HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
             st.n_pair_launches += 1;
         }
 #ifdef UMIHIP_DEV
@@ -1113,6 +1119,15 @@ class Pipeline {
             HIP_TRY(hipEventElapsedTime(&st.ms_collapse, ev[2], ev[3]));
             HIP_TRY(hipEventElapsedTime(&st.ms_finalize, ev[3], ev[4]));
             HIP_TRY(hipEventElapsedTime(&st.ms_total, ev[0], ev[4]));
+            // the kernel that does the call's pair work, by itself: the segment index's pair kernel
+            // where a deep position is in the call, else the fused small-bucket kernel
+            if (seg_timed) {
+                HIP_TRY(hipEventElapsedTime(&st.ms_kernel, ev[7], ev[8]));
+                st.kernel_id = UMI_KERNEL_SEG_PAIRS;
+            } else if (fused_ran) {
+                HIP_TRY(hipEventElapsedTime(&st.ms_kernel, ev[5], ev[6]));
+                st.kernel_id = UMI_KERNEL_FUSED;
+            }
         }
         return UMI_OK;
     }
@@ -1274,6 +1289,10 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
         return;
     }
     int rc;
+    // UMIHIP_TIMING=1: where the wall time of a sharded host-buffer call goes, per device, on stderr
+    const bool timing = getenv("UMIHIP_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     if ((rc = sub->sh_in.reserve(in_bytes)) || (rc = sub->sh_out.reserve(out_bytes))) return fail_here(rc);
     uint64_t at = 0;
     for (uint64_t b : mine) {
@@ -1284,6 +1303,7 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
         at += len;
     }
     umi_stats st;
+    const double t1 = now();
     rc = dedup_batch_single(sub, (const uint64_t *)(sub->sh_in.p + o_keys),
                             nmask ? (const uint64_t *)(sub->sh_in.p + o_nmask) : nullptr,
                             (const int32_t *)(sub->sh_in.p + o_freq), sub->sh_boff.data(), mine.size(), umi_len, k,
@@ -1291,6 +1311,7 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
                             root ? (uint32_t *)(sub->sh_out.p + o_root) : nullptr, &st);
     if (rc) return fail_here(rc);
     res.st = st;
+    const double t2 = now();
     // back to the caller's index space: a bucket's entries keep their order, a root index moves
     // with its bucket
     at = 0;
@@ -1304,6 +1325,10 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
         }
         at += len;
     }
+    if (timing)
+        fprintf(stderr, "umihip multi: device %d: %llu entries in %zu buckets: host gather %.4f s, call (H2D + GPU + D2H) "
+                        "%.4f s of which GPU %.3f ms, host scatter %.4f s\n",
+                sub->device, (unsigned long long)n_local, mine.size(), t1 - t0, t2 - t1, st.ms_total, now() - t2);
 }
 
 // the multi-device split of a call whose work is one giant bucket
@@ -1496,7 +1521,7 @@ extern "C" {
 
 const char *umi_last_error(void) { return g_err.c_str(); }
 
-int umi_abi_version(void) { return 1; }
+int umi_abi_version(void) { return UMI_ABI_VERSION; }
 
 int umi_ctx_create(int device_id, umi_ctx **out)
 {
@@ -1522,7 +1547,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (err == hipSuccess)
         err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES);
-    for (int i = 0; i < 8 && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < umi_ctx::N_EVENTS && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
     if (err != hipSuccess) {
         umi_ctx_destroy(ctx);
         return fail(UMI_ERR_HIP, "context setup failed: %s", hipGetErrorString(err));
@@ -1557,7 +1582,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     ctx->h_tasks.release();
     ctx->h_plan.release();
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < umi_ctx::N_EVENTS; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -261,6 +261,7 @@ constexpr uint32_t SEG_PRIV_CAP = 512; // = the LDS edge stage of a block
 int seg_pair_blocks_per_cu(bool key32, bool has_n, bool ckey);
 hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, float percentage,
                             uint32_t part, uint32_t n_parts, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_seg_edge_append(const PairArgs &a, const SegArgs &g, uint32_t n_blocks, hipStream_t s);
 
 // ---- multi-word keys (umihip_wide.hip): umi_len 22..85, n_words = 2..4 words per key, entry-major
 hipError_t launch_wide_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,

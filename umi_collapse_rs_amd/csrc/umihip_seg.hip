@@ -866,6 +866,14 @@ hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, flo
         if (has_n) seg_pair_kernel<uint64_t, true, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
         else seg_pair_kernel<uint64_t, false, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
     }
+    return hipGetLastError();
+}
+
+// what the pair kernel's blocks still held in their stages when they ended: from their private
+// slots to the list
+hipError_t launch_seg_edge_append(const PairArgs &a, const SegArgs &g, uint32_t n_blocks, hipStream_t s)
+{
+    if (g.n_chunks == 0 || n_blocks == 0) return hipSuccess;
     seg_edge_scan_kernel<<<1, 1024, 0, s>>>(g.priv_cnt, n_blocks, a.counters);
     seg_edge_move_kernel<<<n_blocks, 64, 0, s>>>(g, g.priv_cnt, n_blocks, a.edges,
                                                  a.mode == MODE_NEIGHBOURS ? a.edge_dist : nullptr, a.edge_cap,
