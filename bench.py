@@ -304,7 +304,8 @@ class Resident:
 def roofline_of(wl, n, stats, ms_step):
     """the roofline of the kernel that does the step's pair work, from its
     ALGORITHMIC work and its duration measured live with HIP events in this run (umi_stats.ms_kernel,
-    recorded on the stream the kernel is launched on).  A deep position (seg_pair_kernel) is bound by
+    recorded on the stream the kernel is launched on, in a block of steps of its own: see measure).
+    A deep position (seg_pair_kernel) is bound by
     integer VALU work -- 3 lane-ops per pair it evaluates (xor, popcount, compare), 0 algorithmic HBM
     bytes per pair; a batch of small positions (the fused small_bucket_kernel) streams 16 B per unique
     UMI and is priced against HBM.  traffic: fabric-side bytes of one launch from the committed
@@ -355,23 +356,36 @@ def roofline_of(wl, n, stats, ms_step):
     return out
 
 
-def measure(res, steps, warmup):
-    """warmup untimed steps, then `steps` timed ones; the block of one workload's result."""
+def measure(res, steps, warmup, profile=True):
+    """warmup untimed steps, then `steps` timed ones; the block of one workload's result.
+    The timed steps run with the library's event records off: a hipEventRecord between two kernels
+    costs the stream ~5 us, and a call records up to nine -- 0.04 ms of a 0.14 ms step.  The phase
+    times and the duration of the kernel the roofline is quoted on come from a second block of the
+    same `steps` steps, on the same stream, with the records on (`ms_per_step_with_events`)."""
     import torch
+    res.ctx.set_option("profile", 0)
     for _ in range(warmup):
         res.step()
     res.drain_gathers()
-    dt, stats = res.timed(steps)
+    dt, stats_plain = res.timed(steps)
     kept_n = int(res.d_kept[:res.n].sum().item())
-    assert kept_n == stats[-1]["n_kept"]
+    assert kept_n == stats_plain[-1]["n_kept"]
     res.check_gathered(kept_n)
     ms_step = dt / steps * 1e3
+    stats, ms_events = stats_plain, None
+    if profile:
+        res.ctx.set_option("profile", 1)
+        res.step()
+        res.drain_gathers()
+        dt_ev, stats = res.timed(steps)
+        ms_events = dt_ev / steps * 1e3
+        res.ctx.set_option("profile", 0)
     mean = lambda f: float(np.mean([s[f] for s in stats]))
     s0 = stats[-1]
     wl = res.wl
     out = {
         "workload": "%s, --data naive --algo dir -k %d -p %g" % (wl["workload"], wl["k"], res.p),
-        "ms_per_step": ms_step, "steps": steps,
+        "ms_per_step": ms_step, "steps": steps, "ms_per_step_with_events": ms_events,
         "value": res.w_total * steps / dt, "unit": "UMI-pair comparisons/s (effective: W / t)",
         "value_executed": s0["n_pairs_evaluated"] * (1 if res.split else res.world) * steps / dt,
         "walked_fraction": min(1.0, s0["n_pairs_evaluated"] / max(res.w_local, 1)) if res.w_local else None,
@@ -409,6 +423,9 @@ def main():
                          "uniform UMIs, 2m = one deep position from the molecule model, 3 = 10M reads in 100k "
                          "positions, 4 = one GPU's share of the 8-GPU config (12.5M reads in 125k positions), 5 = "
                          "one GPU's share of 50M reads with 20-bp UMIs, k=2")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="no HIP events inside the library's calls (phases_ms and the roofline's kernel time are then "
+                         "missing): what the event records cost the step")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1 rehearsal of the N>1 step: a process group of one rank is formed (RCCL unless "
                          "BENCH_BACKEND says otherwise) and every step packs and all-gathers its mask")
@@ -454,7 +471,7 @@ def main():
     else:
         also = [] if args.also == "none" else [c for c in args.also.split(",") if c]
 
-    ctx = umi.Context(dev_index, profile=True)
+    ctx = umi.Context(dev_index)
     opts = {}
     for o in args.opt:
         name, val = o.split("=")
@@ -464,7 +481,7 @@ def main():
     # ---- the top-level workload
     wl = make_workload(cfg, 0 if split else rank, args.reads or None)
     res = Resident(wl, ctx, dev, world, rank, dist, args.p, split, coll)
-    block, dt, stats, kept_n = measure(res, args.steps, args.warmup)
+    block, dt, stats, kept_n = measure(res, args.steps, args.warmup, not args.no_profile)
     kept_ref = res.d_kept.clone()
     n, st = res.n, wl["st"]
     ms_step = block["ms_per_step"]
@@ -480,7 +497,7 @@ def main():
     # (no n-gram partition)
     brute = None
     if extras and world == 1 and wl["one_position"] and n <= 1_200_000:
-        cb = umi.Context(dev_index, profile=True)
+        cb = umi.Context(dev_index)
         try:
             cb.set_option("seg_index", 0)
             res.step(cb)
@@ -549,7 +566,7 @@ def main():
     for c in also:
         w2 = make_workload(c, rank)
         r2 = Resident(w2, ctx, dev, world, rank, dist, args.p, False, coll)
-        b2, _, _, _ = measure(r2, args.steps, args.warmup)
+        b2, _, _, _ = measure(r2, args.steps, args.warmup, not args.no_profile)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # (a prefix of buckets / a 40,000-UMI cut that the oracle finishes in about a second)
             b2["cpu_baseline"] = cpu_baseline(w2, 40_000 if w2["one_position"] else 5_000, args.p, all_cores=False)
@@ -567,7 +584,7 @@ def main():
             "value": block["value"],
             "unit": "UMI-pair comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True,
+            "ms_per_step": ms_step, "ms_per_step_with_events": block["ms_per_step_with_events"], "higher_is_better": True,
             "scaling": "strong" if split else "weak",
             "vs_baseline": None, "dtype": "u32" if wl["umi_len"] <= 16 else "u64", "data": "synthetic",
             "config": {"workload": block["workload"], "baseline_config": cfg, "standard": std,

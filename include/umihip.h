@@ -99,6 +99,7 @@ const char *umi_last_error(void);
  *   "profile"        0/1: record HIP events, fill the ms_* fields of umi_stats
  *   "edge_capacity"  initial capacity of the permitted-pair list, entries (it grows by itself)
  *   "fused_max"      0..128 (default 128): largest bucket the fused one-wave-per-bucket kernel takes
+ *   "fused_blocks"   1..16 (default 6): 256-thread blocks per CU of that kernel's persistent grid
  *   "fused_sliced"   0/1 (default 1): that kernel's bit-sliced body for k <= 3 (0: columns one by one)
  *   "small_max"      (default 1024) largest bucket taken as 64-row popcount chunks; above, 2048-row tiles
  *   "seg_index"      0/1 (default 1): buckets of at least "seg_min" entries (default 512) are cut into
@@ -137,9 +138,12 @@ int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *key
  *      n_words = ceil(3 * umi_len / 64) words per key, entry-major (keys[i * n_words + w] =
  *      bits[w] of entry i; nmask likewise or NULL), everything else as in umi_dedup_batch.  The
  *      distance is the reference's per-word arithmetic (src/utils/bitset.rs:77-91), a base that
- *      straddles two words included.  Every pair of a position is evaluated exactly (no filter,
- *      no n-gram partition): no BASELINE config has such UMIs.  umi_encode_umis_wide is to_bitset
- *      (src/utils/mod.rs:63-83) for these lengths, host code. */
+ *      straddles two words included.  Positions of up to 128 UMIs go through the fused kernel (all
+ *      words' bases sliced), deep positions through the n-gram partition of the first word's 21 bases
+ *      (two UMIs within k overall are within k there) with every candidate pair decided on all words,
+ *      the ones in between through an exact all-pairs kernel; a multi-device context shards the
+ *      positions as for one-word keys.  Dual 12 + 12 UMIs are the 24-base, two-word case.
+ *      umi_encode_umis_wide is to_bitset (src/utils/mod.rs:63-83) for these lengths, host code. */
 int umi_encode_umis_wide(const uint8_t *ascii, uint64_t n, int umi_len, int n_words, uint64_t *keys,
                          uint64_t *nmask);
 int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words,
@@ -259,6 +263,10 @@ int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges,
  * dist <= max_edits on the GPU once. */
 int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                  uint32_t n, int umi_len, int max_edits, umi_data **out);
+/* The same for keys of n_words = ceil(3 * umi_len / 64) words (umi_len up to UMI_MAX_WIDE_UMI_LEN,
+ * entry-major as in umi_dedup_batch_wide); remove_near / contains / free as above. */
+int umi_data_new_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                      uint32_t n, int umi_len, int max_edits, umi_data **out);
 /* DataStruct::remove_near (naive.rs:26-40): removes and returns every remaining
  * entry o with dist(query,o) <= k && (dist == 0 || freq[o] <= max_freq).
  * k must be <= max_edits.  out_idx has capacity n; ascending index order. */

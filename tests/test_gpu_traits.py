@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 def test_hipnaive_remove_near_sequence_matches_naive():
     import umi_collapse_rs_amd as umi
     rng = np.random.default_rng(8)
-    for L, k, n_frac in ((8, 1, 0.0), (8, 2, 0.05), (12, 1, 0.0), (20, 3, 0.02)):
+    for L, k, n_frac in ((8, 1, 0.0), (8, 2, 0.05), (12, 1, 0.0), (20, 3, 0.02), (24, 2, 0.02), (50, 1, 0.0)):
+        # (24 and 50 bases: keys of two and three words, umi_data_new_wide)
         umis, freq = random_bucket(rng, 60, L, err=0.1, n_frac=n_frac)
         d = umi.HipNaive.new(dict(zip(umis, freq)), L, k)
         o = orc.Naive(umis, freq)

@@ -99,3 +99,59 @@ def test_wide_contract_violations(ctx):
         ctx.dedup_batch_wide(keys, nm, np.array([1, 2], np.int32), off, 22)
     with pytest.raises(umi.UmiHipError):  # one word too few for the length
         ctx.dedup_batch_wide(keys[:, :1].copy(), None, np.array([1, 1], np.int32), off, 22)
+
+
+@pytest.mark.parametrize("L,k,n_frac,words", [(24, 1, 0.0, 2), (24, 2, 0.004, 2), (45, 1, 0.002, 3), (70, 3, 0.0, 4)])
+def test_wide_keys_deep_positions_through_the_segment_index(ctx, L, k, n_frac, words):
+    """Positions of a few thousand UMIs of more than 21 bases: the segment index works on the first
+    word's 21 bases (a pair within k overall is within k there) and every filter hit is decided on all
+    words; next to them buckets for the fused kernel (<= 128) and for the exact chunk kernel.  A dual
+    12 + 12 UMI is the 24-bp case.  Against the oracle, and against the all-pairs path (seg_index = 0)."""
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(7 * L + k)
+    parts = [make_batch(rng, 30, L, 50, err=0.03, n_frac=n_frac)]
+    for n_mol in (1500, 300, 700):  # ~3,500 / ~700 / ~1,600 entries: segment index; chunk kernel; segment index
+        # clustered: few centres with many error copies, so that neighbours within k exist at every freq
+        centres = rng.integers(0, 4, (max(2, n_mol // 12), L))
+        out = {}
+        for _ in range(n_mol * 3):
+            u = centres[rng.integers(len(centres))].copy()
+            flip = rng.random(L) < 0.04
+            u[flip] = rng.integers(0, 4, int(flip.sum()))
+            t = [ALPHA[c] for c in u]
+            for b in np.nonzero(rng.random(L) < n_frac)[0]:
+                t[b] = "N"
+            t = "".join(t)
+            out[t] = out.get(t, 0) + 1
+        umis = list(out)
+        umis, freq, _ = canonical(umis, [out[u] for u in umis])
+        kk, mm = orc.encode_keys_wide(umis)
+        parts.append((kk, mm, np.array(freq, np.int32), np.array([0, len(umis)], np.uint64)))
+    keys = np.concatenate([p_[0] for p_ in parts]); nm = np.concatenate([p_[1] for p_ in parts])
+    fr = np.concatenate([p_[2] for p_ in parts])
+    offs, base = [np.zeros(1, np.uint64)], np.uint64(0)
+    for p_ in parts:
+        offs.append(p_[3][1:] + base)
+        base = base + p_[3][-1]
+    off = np.concatenate(offs)
+    assert keys.shape[1] == words and np.diff(off.astype(np.int64)).max() > 2000
+    okept, oroot, _ = orc.dedup_batch_wide(keys, nm, fr, off, L, k, 0.5)
+    nmask = nm if nm.any() else None
+    kept, root, st = ctx.dedup_batch_wide(keys, nmask, fr, off, L, k, 0.5)
+    assert (kept == okept).all(), np.nonzero(kept != okept)[0][:10]
+    assert (root == oroot).all()
+    assert st["n_pairs_evaluated"] < st["n_pairs"]  # the partition did prune
+    c2 = umi.Context(0)
+    try:
+        c2.set_option("seg_index", 0)
+        c2.set_option("fused_max", 0)
+        kept2, root2, st2 = c2.dedup_batch_wide(keys, nmask, fr, off, L, k, 0.5)
+        assert (kept2 == okept).all() and (root2 == oroot).all() and st2["n_pairs_evaluated"] > st["n_pairs_evaluated"]
+        multi = umi.Context([0, 0, 0])
+        try:
+            mk, mr, mst = multi.dedup_batch_wide(keys, nmask, fr, off, L, k, 0.5)  # sharded over three workers
+            assert (mk == okept).all() and (mr == oroot).all() and mst["n_kept"] == st["n_kept"]
+        finally:
+            multi.close()
+    finally:
+        c2.close()

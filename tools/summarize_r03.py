@@ -21,7 +21,7 @@ import bench  # noqa: E402  (source_sha256)
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "head"
 BASE = os.path.join(ROOT, "gpurun_out", "prof_r03")
-STEPS = 7  # --steps 5 --warmup 2 of tools/profile_r03.sh
+STEPS = 13  # --steps 5 --warmup 2: 2 + 5 plain steps, then 1 + 5 with the event records on (bench.py measure)
 OUT = os.path.join(ROOT, "profiles", "r03_counters.json")
 
 PHASES = (("prep", ("prep_kernel", "bucket_rise", "seg_scan", "seg_scatter", "seg_count", "seg_hist", "iota", "rocprim")),

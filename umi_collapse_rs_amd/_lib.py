@@ -78,6 +78,8 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "umi_data_new": (C.c_int, [C.c_void_p, _u64p, _u64p, _i32p, C.c_uint32, C.c_int, C.c_int,
                                C.POINTER(C.c_void_p)]),
+    "umi_data_new_wide": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int, _i32p, C.c_uint32, C.c_int, C.c_int,
+                                    C.POINTER(C.c_void_p)]),
     "umi_data_remove_near": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int32, _u32p, _u32p]),
     "umi_data_contains": (C.c_int, [C.c_void_p, C.c_uint32]),
     "umi_data_free": (None, [C.c_void_p]),

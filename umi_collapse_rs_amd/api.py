@@ -230,10 +230,18 @@ class HipNaive:
         self._umis = list(umi_freq.keys())
         self._index = {u: i for i, u in enumerate(self._umis)}
         freq = np.array([umi_freq[u] for u in self._umis], dtype=np.int32)
-        keys, nmask = to_bitset(self._umis, umi_length) if self._umis else (
-            np.zeros(0, np.uint64), np.zeros(0, np.uint64))
         self._n = len(self._umis)
         h = C.c_void_p()
+        if umi_length > _lib.UMI_MAX_UMI_LEN:  # keys of several words (bitset.rs:17-27)
+            words = (3 * umi_length + 63) // 64
+            keys, nmask = to_bitset_wide([u if isinstance(u, str) else u.decode() for u in self._umis], umi_length) \
+                if self._umis else (np.zeros((0, words), np.uint64), np.zeros((0, words), np.uint64))
+            check(load().umi_data_new_wide(ctx._h, ptr(keys, C.c_uint64), ptr(nmask, C.c_uint64) if nmask.any() else None,
+                                           words, ptr(freq, C.c_int32), self._n, umi_length, max_edits, C.byref(h)))
+            self._h = h
+            return self
+        keys, nmask = to_bitset(self._umis, umi_length) if self._umis else (
+            np.zeros(0, np.uint64), np.zeros(0, np.uint64))
         check(load().umi_data_new(ctx._h, ptr(keys, C.c_uint64),
                                   ptr(nmask, C.c_uint64) if nmask.any() else None,
                                   ptr(freq, C.c_int32), self._n, umi_length, max_edits,

@@ -75,8 +75,6 @@ struct DevBuf {
 };
 
 constexpr int MAX_ROUNDS = 1 << 20;
-constexpr int DAG_ROUNDS = 3; // one-way rounds enqueued before the host first looks (freq at least
-                              // halves along a one-way pair at p <= 0.5: depth 2 at config 2)
 
 // grow-only pinned host buffer; every write goes through put(), which checks the extent
 struct PinnedBuf {
@@ -140,6 +138,7 @@ struct umi_ctx {
     uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 128 per CU; items are dealt
                                // statically over them, the dispatcher evens out the rest)
     uint32_t fused_max = FUSED_MAX;
+    uint32_t fused_blocks = 6; // 256-thread blocks per CU of the fused kernel's persistent grid
     bool fused_sliced = true;
     int bs_unit = 2;
     bool bs_sorted = LEGACY_DEFAULT; // sort large buckets by key and reuse prefix state along column runs
@@ -163,8 +162,13 @@ struct umi_ctx {
     DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, counters, boff, status, blocked;
     DevBuf plan_tables; // ranges, segment descriptors, scan chunks, popcount tile tasks: one upload
     DevBuf bs_tasks, plane_tasks, planes, tab_rows, tab_items;
-    DevBuf seg_bin_cnt, seg_bin_start, seg_chunk_sums, seg_tasks, seg_sub_rec, seg_priv_edges, seg_priv_dist, seg_priv_cnt;
-    PinnedBuf h_plan;
+    DevBuf collapse_flags; // barrier flag words of the fused collapse kernel's blocks
+    uint32_t collapse_epoch = 0;
+    DevBuf seg_bin_cnt, seg_bin_start, seg_tasks, seg_sub_rec, seg_priv_edges, seg_priv_dist, seg_priv_cnt;
+    PinnedBuf h_plan_alt[2]; // staging of the plan's tables, in turn; [plan_flip ^ 1] = what plan_tables holds
+    int plan_flip = 0;
+    size_t plan_uploaded = 0;
+    const void *plan_uploaded_to = nullptr;
     int n_cus = 256;
     DevBuf fkey_sorted, perm, iota, sort_tmp, sample_pos, sample_out; // prune mode
     bool prune = false;
@@ -180,6 +184,8 @@ struct umi_ctx {
     unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES)
     uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
     uint32_t *d_changed() const { return (uint32_t *)(counters.as<unsigned long long>() + CNT_COUNT); }
+    uint32_t *h_sync() const { return (uint32_t *)((char *)h_counters + CTRL_SYNC_OFF); }
+    uint32_t *d_sync() const { return (uint32_t *)((char *)counters.p + CTRL_SYNC_OFF); }
     static constexpr int N_EVENTS = 10;
     hipEvent_t ev[N_EVENTS] = {};
 };
@@ -307,8 +313,10 @@ class Pipeline {
     // the caller keeps a copy of bucket_off in device memory (resident like keys and freq): no
     // staging copy, no upload
     void use_device_table(const uint64_t *d_table) { d_boff_caller = d_table; }
-    // keys of n_words > 1 words per entry (umi_len > 21): the plain exact all-pairs kernel of
-    // umihip_wide.hip takes every bucket (no fused kernel, no filter keys, no segment index)
+    // keys of n_words > 1 words per entry (umi_len > 21).  Filter keys and the segment index work on
+    // the first word's 21 bases (two UMIs within k overall are within k there), every hit is decided
+    // on all words; the fused kernel slices all words' bases; buckets in between go to the exact
+    // all-pairs kernel of umihip_wide.hip.
     void use_wide_keys(int words) { n_words = words; }
 
   private:
@@ -319,6 +327,7 @@ class Pipeline {
     const uint64_t *d_boff_caller = nullptr;
     int n_words = 1;
     bool wide() const { return n_words > 1; }
+    int plan_umi_len() const { return wide() ? 21 : umi_len; } // bases the filter keys hold
     const uint64_t *d_boff() const { return d_boff_caller ? d_boff_caller : ctx->boff.as<uint64_t>(); }
     uint64_t n_buckets;
     uint32_t n;
@@ -337,12 +346,14 @@ class Pipeline {
                                   // after the pair kernels (multi-GPU split of one call's pairs)
     uint64_t task_counter = 0;    // running index over all tile tasks, for that split
     bool prune = false, drained = false, fused_ran = false, seg_timed = false;
+    size_t zero_behind_control = 0; // bytes of the segment index's counters that sit behind the control block
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
     uint64_t n_edges = 0;  // entries the pair kernels appended to the edge list
     uint64_t n_direct = 0; // symmetric pairs united where they were found
     uint64_t seg_tasks_made = 0;
+    uint32_t seg_grid = 0; // blocks of the segment index's pair kernel = its private edge slots
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
     [[maybe_unused]] const uint32_t *bs_perm = nullptr;
@@ -372,18 +383,29 @@ class Pipeline {
     int run_stages()
     {
         int rc;
-        if (wide()) fused_max = 0;
+        if (wide() && (mode != MODE_DIRECTIONAL || k > 3)) fused_max = 0; // (the wide fused kernel: directional, sliced)
         // The fused kernel needs nothing from the plan (it walks the bucket table itself and does
         // everything for its buckets): with many buckets it is enqueued first, and the host walks
         // the table -- tile tasks, pair counts, the entry ranges left for prep and finalize --
         // while it runs.  With few buckets the plan is there at once and says whether any bucket
         // is the fused kernel's at all.
-        if ((rc = reserve_core())) return rc;
         const bool plan_first = n_buckets <= 4096;
+        if (plan_first) {
+            // (a table that steps backwards must not reach the planner)
+            for (uint64_t b = 0; b < n_buckets; b++)
+                if (bucket_off[b + 1] < bucket_off[b])
+                    return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
+            plan_host();
+            // the segment index's bin counters and scan words go behind the control block: one fill
+            // clears both
+            if (pl.seg_parts && need_pairs) zero_behind_control = seg_zero_bytes();
+        }
+        if ((rc = reserve_core())) return rc;
         if ((rc = upload_table(!plan_first))) return rc;
-        if (plan_first) plan_host();
         if (plan_first && pl.n_fused && (rc = fused_stage(0, n_buckets))) return rc;
         if (!plan_first) plan_host();
+        if (ctx->table_pass.bad_at != ~0ull)
+            return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)ctx->table_pass.bad_at);
         if ((rc = upload_plan())) return rc;
         if ((rc = prep_stage())) return rc;
 #ifdef UMIHIP_DEV
@@ -427,7 +449,7 @@ class Pipeline {
 
     int read_control()
     {
-        HIP_TRY(hipMemcpyAsync(ctx->h_counters, d_cnt, CTRL_BYTES, hipMemcpyDeviceToHost, s));
+        HIP_TRY(launch_control_to_host(d_cnt, ctx->h_counters, CTRL_BYTES, s));
         HIP_TRY(hipStreamSynchronize(s));
         const unsigned long long bad =
             ctx->h_counters[CNT_ERROR] + (ctx->h_counters[CNT_RISES] - ctx->h_counters[CNT_START_RISES]);
@@ -446,7 +468,7 @@ class Pipeline {
         int rc;
         if ((rc = ctx->fkey.reserve((size_t)n * 8)) || (rc = ctx->thr.reserve((size_t)n * 4)) ||
             (rc = ctx->label.reserve((size_t)n * 4)) || (rc = ctx->lab.reserve((size_t)n * 4)) ||
-            (rc = ctx->counters.reserve(CTRL_BYTES)) || (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
+            (rc = ctx->counters.reserve(CTRL_BYTES + zero_behind_control)) || (rc = ctx->boff.reserve((n_buckets + 1) * 8)))
             return rc;
         if (mode == MODE_ADJACENCY && need_pairs)
             if ((rc = ctx->status.reserve(n)) || (rc = ctx->blocked.reserve(n))) return rc;
@@ -460,9 +482,9 @@ class Pipeline {
     {
         // (the table is monotone: upload_table has looked)
         scan_table_range(bucket_off, 0, n_buckets, fused_max, nullptr, ctx->table_pass);
-        const bool seg_on = ctx->seg_index && need_pairs && !ctx->prune && !wide();
+        const bool seg_on = ctx->seg_index && need_pairs && !ctx->prune;
         build_plan(bucket_off, n_buckets, wide() ? 0x7FFFFFFFu : ctx->small_max, ctx->use_bitslice && k <= BS_MAX_K && !wide(),
-                   umi_len, fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
+                   plan_umi_len(), fused_max, ctx->prune, ctx->bs_sorted && ctx->bs_unit == 2 && need_pairs,
                    ctx->bs_tables && key32, ctx->bs_tab_min_run, seg_on ? std::max(ctx->seg_min, 1u) : 0u, k, key32, pl,
                    &ctx->table_pass);
         prune = ctx->prune && need_pairs && !pl.bs_buckets.empty() && !wide();
@@ -470,6 +492,12 @@ class Pipeline {
         keep_my_share(pl.big_tasks);
         st.max_bucket = pl.max_bucket;
         st.n_pairs = pl.n_pairs;
+    }
+
+    size_t seg_bins_bytes() const { return (pl.seg_bins * 4 + 15) & ~(size_t)15; }
+    size_t seg_zero_bytes() const
+    {
+        return (seg_bins_bytes() + (1 + pl.seg_chunks.size()) * sizeof(unsigned long long) + 15) & ~(size_t)15;
     }
 
     // the plan's tables -- entry ranges, segment descriptors and scan chunks, popcount tile tasks --
@@ -490,15 +518,27 @@ class Pipeline {
         const size_t o_small = place(pl.small_tasks.size() * sizeof(PairTask));
         const size_t o_big = place(pl.big_tasks.size() * sizeof(PairTask));
         const size_t total = std::max<size_t>(off, 64);
-        if ((rc = ctx->h_plan.reserve(total)) || (rc = ctx->plan_tables.reserve(total))) return rc;
-        if ((rc = ctx->h_plan.put(o_ranges, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask))) ||
-            (rc = ctx->h_plan.put(o_segs, pl.segs.data(), pl.segs.size() * sizeof(SegDesc))) ||
-            (rc = ctx->h_plan.put(o_chunks, pl.seg_chunks.data(), pl.seg_chunks.size() * sizeof(SegScanChunk))) ||
-            (rc = ctx->h_plan.put(o_blocks, pl.seg_blocks.data(), pl.seg_blocks.size() * sizeof(SegBlock))) ||
-            (rc = ctx->h_plan.put(o_small, pl.small_tasks.data(), pl.small_tasks.size() * sizeof(PairTask))) ||
-            (rc = ctx->h_plan.put(o_big, pl.big_tasks.data(), pl.big_tasks.size() * sizeof(PairTask))))
+        // (two staging blocks in turn: what the previous call uploaded stays comparable -- a host that
+        // calls again with the same bucket table, a resident job's next step, uploads nothing)
+        PinnedBuf &hp = ctx->h_plan_alt[ctx->plan_flip];
+        if ((rc = hp.reserve(total)) || (rc = ctx->plan_tables.reserve(total))) return rc;
+        if (off) memset(hp.p, 0, off); // (padding between the tables: compared too)
+        if ((rc = hp.put(o_ranges, pl.ranges.data(), pl.ranges.size() * sizeof(RangeTask))) ||
+            (rc = hp.put(o_segs, pl.segs.data(), pl.segs.size() * sizeof(SegDesc))) ||
+            (rc = hp.put(o_chunks, pl.seg_chunks.data(), pl.seg_chunks.size() * sizeof(SegScanChunk))) ||
+            (rc = hp.put(o_blocks, pl.seg_blocks.data(), pl.seg_blocks.size() * sizeof(SegBlock))) ||
+            (rc = hp.put(o_small, pl.small_tasks.data(), pl.small_tasks.size() * sizeof(PairTask))) ||
+            (rc = hp.put(o_big, pl.big_tasks.data(), pl.big_tasks.size() * sizeof(PairTask))))
             return rc;
-        if (off) HIP_TRY(hipMemcpyAsync(ctx->plan_tables.p, ctx->h_plan.p, off, hipMemcpyHostToDevice, s));
+        const PinnedBuf &prev = ctx->h_plan_alt[ctx->plan_flip ^ 1];
+        const bool same = off && ctx->plan_uploaded == off && ctx->plan_uploaded_to == ctx->plan_tables.p &&
+                          prev.p && prev.cap >= off && memcmp(prev.p, hp.p, off) == 0;
+        if (off && !same) {
+            HIP_TRY(hipMemcpyAsync(ctx->plan_tables.p, hp.p, off, hipMemcpyHostToDevice, s));
+            ctx->plan_uploaded = off;
+            ctx->plan_uploaded_to = ctx->plan_tables.p;
+            ctx->plan_flip ^= 1; // (this block now holds what the device holds)
+        }
         const char *d = (const char *)ctx->plan_tables.p;
         d_ranges = (const RangeTask *)(d + o_ranges);
         d_segs = (const SegDesc *)(d + o_segs);
@@ -517,8 +557,10 @@ class Pipeline {
                 return fail(UMI_ERR_NOMEM, "segment index of this call too large (set seg_index=0)");
             const size_t m = (size_t)pl.seg_entries * (size_t)pl.seg_parts;
             if (pl.segs.size() >= (1u << 24)) return fail(UMI_ERR_NOMEM, "too many segments in one call (set seg_index=0)");
-            if ((rc = ctx->seg_bin_cnt.reserve(pl.seg_bins * 4)) || (rc = ctx->seg_bin_start.reserve(pl.seg_bins * 4)) ||
-                (rc = ctx->seg_chunk_sums.reserve(pl.seg_chunks.size() * sizeof(uint2))) ||
+            // (the bin counters and, behind them, the scan's ticket and status words: one block, one memset)
+            const size_t bins_bytes = seg_bins_bytes(), zero_bytes = seg_zero_bytes();
+            if ((!zero_behind_control && (rc = ctx->seg_bin_cnt.reserve(zero_bytes))) ||
+                (rc = ctx->seg_bin_start.reserve(pl.seg_bins * 4)) ||
                 (rc = ctx->seg_tasks.reserve(pl.seg_task_cap * sizeof(SegTask))) ||
                 (rc = ctx->seg_sub_rec.reserve(m * sizeof(SegRec32))))
                 return rc;
@@ -527,15 +569,17 @@ class Pipeline {
             seg.chunks = d_chunks;
             seg.n_chunks = (uint32_t)pl.seg_chunks.size();
             seg.n_parts = pl.seg_parts;
-            seg.bin_cnt = ctx->seg_bin_cnt.as<uint32_t>();
+            seg.bin_cnt = zero_behind_control ? (uint32_t *)((char *)ctx->counters.p + CTRL_BYTES) : ctx->seg_bin_cnt.as<uint32_t>();
             seg.bin_start = ctx->seg_bin_start.as<uint32_t>();
-            seg.chunk_sums = ctx->seg_chunk_sums.as<uint2>();
+            seg.scan_state = (unsigned long long *)((char *)seg.bin_cnt + bins_bytes);
             seg.tasks = ctx->seg_tasks.as<SegTask>();
             seg.task_cap = (uint32_t)pl.seg_task_cap;
             seg.sub_rec = ctx->seg_sub_rec.p;
             seg.ranges = d_ranges;
             seg.n_ranges = (uint32_t)pl.ranges.size();
-            seg.umi_len = umi_len;
+            seg.umi_len = plan_umi_len();
+            seg.key_words = n_words;
+            seg.full_umi_len = umi_len;
             seg.use_ckey = key32 && ctx->seg_ckey && pl.seg_max_rest <= 10 ? 1u : 0u;
             if (ctx->seg_lds && pl.seg_max_bins <= SEG_LDS_BINS && !pl.seg_blocks.empty()) {
                 seg.blocks = d_seg_blocks;
@@ -543,7 +587,7 @@ class Pipeline {
                 seg.lds_bins = pl.seg_max_bins;
                 seg.parts_per_pass = std::max(1u, std::min({4u, (uint32_t)pl.seg_parts, SEG_LDS_BINS / std::max(1u, pl.seg_max_bins)}));
             }
-            HIP_TRY(hipMemsetAsync(seg.bin_cnt, 0, pl.seg_bins * 4, s));
+            if (!zero_behind_control) HIP_TRY(hipMemsetAsync(seg.bin_cnt, 0, zero_bytes, s));
         }
         return UMI_OK;
     }
@@ -555,7 +599,7 @@ class Pipeline {
     int upload_table(bool fuse)
     {
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        HIP_TRY(hipMemsetAsync(d_cnt, 0, CTRL_BYTES, s));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, CTRL_BYTES + zero_behind_control, s));
         // the bucket table goes through a pinned buffer: a true async DMA instead of the
         // runtime's staged copy of pageable memory (it is on the critical path of prep)
         if (ctx->h_boff_cap < n_buckets + 1) {
@@ -580,12 +624,11 @@ class Pipeline {
         for (uint64_t c = 0; c < pieces; c++) {
             const uint64_t b0 = n_buckets * c / pieces, b1 = n_buckets * (c + 1) / pieces;
             uint64_t prev = bucket_off[b0], back = 0;
-            if (d_boff_caller) { // (the table is on the device already: nothing to copy)
-                for (uint64_t b = b0; b < b1; b++) {
-                    const uint64_t v = bucket_off[b + 1];
-                    back |= v < prev;
-                    prev = v;
-                }
+            if (d_boff_caller) {
+                // The table is on the device already: nothing to copy, and nothing to look at before
+                // the launch either -- the fused kernel refuses entries that step backwards or lead
+                // outside the arrays by itself, and the host's walk behind the launch (plan_host)
+                // notes the first such bucket: run_stages fails the call on it.
             } else {
                 for (uint64_t b = b0; b < b1; b++) {
                     const uint64_t v = bucket_off[b + 1];
@@ -612,9 +655,22 @@ class Pipeline {
     {
         if (fused_max < 1 || b1 <= b0) return UMI_OK;
         if (prof && !fused_ran) HIP_TRY(hipEventRecord(ctx->ev[5], s));
+        // (label[] of a bucket the fused kernel finishes is read by nobody on the one-synchronisation
+        // path -- its collapse covers the other buckets' ranges only: the store is left out there)
+#ifdef UMIHIP_DEV
+        const bool need_label = true; // (the tile kernels' collapse variants walk label[] of every entry)
+#else
+        const bool need_label = !((mode == MODE_DIRECTIONAL || !need_pairs) && n_parts == 1);
+#endif
+        if (wide())
+            HIP_TRY(launch_small_buckets_wide(d_keys, d_nmask, n_words, d_freq, percentage, d_boff() + b0, (uint32_t)(b1 - b0),
+                                              fused_max, n, d_kept, d_root, k, umi_len, d_cnt,
+                                              (uint32_t)ctx->n_cus * ctx->fused_blocks, s));
+        else
         HIP_TRY(launch_small_buckets(d_keys, d_nmask, d_freq, percentage, d_boff() + b0,
-                                     (uint32_t)(b1 - b0), fused_max, n, ctx->label.as<uint32_t>(), d_kept,
-                                     d_root, k, umi_len, ctx->fused_sliced, mode, adj_max_freq, d_cnt, s));
+                                     (uint32_t)(b1 - b0), fused_max, n, need_label ? ctx->label.as<uint32_t>() : nullptr, d_kept,
+                                     d_root, k, umi_len, ctx->fused_sliced, mode, adj_max_freq, d_cnt,
+                                     (uint32_t)ctx->n_cus * ctx->fused_blocks, s));
         if (prof) HIP_TRY(hipEventRecord(ctx->ev[6], s));
         if (!fused_ran) st.n_pair_launches += 1;
         fused_ran = true;
@@ -625,12 +681,6 @@ class Pipeline {
     // the entries of a segment also count themselves into the bins of its parts
     int prep_stage()
     {
-        if (wide()) {
-            HIP_TRY(launch_wide_prep(d_keys, d_nmask, d_freq, d_ranges, (uint32_t)pl.ranges.size(), n_words, umi_len,
-                                     percentage, ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), d_cnt, s));
-            HIP_TRY(launch_bucket_rise(d_freq, d_boff(), n_buckets, n, d_cnt, s));
-            return UMI_OK;
-        }
         // With the LDS counting sort the segments' entries are prepared by its count kernel; the
         // entry kernel keeps the other buckets' ranges (none at all for a call of deep positions:
         // only the rises at bucket starts are left to count)
@@ -647,10 +697,10 @@ class Pipeline {
         bool other_ranges = false;
         for (const RangeTask &r : pl.ranges) other_ranges = other_ranges || r.seg == SEG_NONE;
         HIP_TRY(launch_prep(d_keys, d_nmask, d_freq, d_boff(), n_buckets, d_ranges,
-                            (uint32_t)pl.ranges.size(), n, fused_max, umi_len, percentage, key32, ctx->fkey.p,
+                            (uint32_t)pl.ranges.size(), n, fused_max, plan_umi_len(), percentage, key32, ctx->fkey.p,
                             ctx->thr.as<int32_t>(), ctx->label.as<uint32_t>(), nullptr, d_cnt,
                             seg.n_chunks && !seg.blocks ? d_segs : nullptr, pl.seg_parts, seg.bin_cnt, s, fold,
-                            !fold || other_ranges));
+                            !fold || other_ranges, std::max({ctx->seg_min, fused_max + 1, 1u}), n_words, umi_len));
         return UMI_OK;
     }
 
@@ -849,7 +899,9 @@ class Pipeline {
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[8], s));
             seg_timed = true;
-            HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
+            seg_grid = blocks;
+            // (the batched directional path reads the blocks' private slots where they are)
+            if (!(one_sync() && seg.uf_parent)) HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
             st.n_pair_launches += 1;
         }
 #ifdef UMIHIP_DEV
@@ -966,14 +1018,39 @@ class Pipeline {
     }
 
     // The batched directional path with one synchronisation: pair kernels, union-find over the
-    // symmetric pairs, DAG_ROUNDS rounds along the one-way pairs, kept mask -- all enqueued behind
-    // one another (the kernels read the edge count on the device), the control block read once.
-    // What the host may find then: the edge list ran over (longer list, pairs and collapse
-    // again), or the last one-way round still moved a label (more rounds, finalize again).
+    // symmetric pairs, then ONE launch for the rest -- forest flattened, rounds along the one-way
+    // pairs until one is quiet, kept mask -- all enqueued behind one another (the kernels read the
+    // edge count on the device), the control block read once.  What the host may find then: the
+    // edge list ran over (longer list, pairs and collapse again); the fused collapse gave up at a
+    // barrier (its grid was not resident at once: the phases again as separate launches); or its
+    // last round still moved a label (more rounds, finalize again).
+    bool slots_direct() const { return pl.seg_parts && seg.uf_parent != nullptr; }
+    CollapseDesc collapse_desc() const
+    {
+        CollapseDesc d;
+        d.parent = ctx->label.as<uint32_t>();
+        d.lab = ctx->lab.as<uint32_t>();
+        d.edges = ctx->edges.as<uint2>();
+        d.edge_cap = cap_used;
+        d.priv_edges = slots_direct() ? seg.priv_edges : nullptr;
+        d.priv_cnt = seg.priv_cnt;
+        d.n_slots = seg_grid;
+        d.ranges = d_ranges;
+        d.n_ranges = (uint32_t)pl.ranges.size();
+        d.n = n;
+        d.kept = d_kept;
+        d.root = d_root;
+        d.counters = d_cnt;
+        d.changed = ctx->d_changed();
+        d.sync = ctx->d_sync();
+        d.flags = ctx->collapse_flags.as<uint32_t>();
+        d.epoch = ctx->collapse_epoch;
+        return d;
+    }
     int run_one_sync()
     {
         int rc;
-        uint32_t *d_label = ctx->label.as<uint32_t>(), *d_lab = ctx->lab.as<uint32_t>();
+        uint32_t *d_label = ctx->label.as<uint32_t>();
         uint32_t *d_changed = ctx->d_changed();
         const bool have_pairs = need_pairs && n_tasks;
         uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
@@ -984,23 +1061,20 @@ class Pipeline {
                 if ((rc = enqueue_pairs(ovf_cap))) return rc;
             }
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[2], s));
-            const uint2 *d_edges = ctx->edges.as<uint2>();
             if (have_pairs) {
                 // symmetric pairs in the list: those of the tile kernels, and the segment index's
                 // when it does not unite them itself
                 if (!seg.uf_parent || legacy_tiles() || !pl.small_tasks.empty() || !pl.big_tasks.empty())
-                    HIP_TRY(launch_uf_union_list(d_edges, d_cnt, cap_used, d_label, cap_used, s));
-                HIP_TRY(launch_uf_flatten(d_label, d_lab, n, s));
-                for (int r = 0; r < DAG_ROUNDS; r++)
-                    HIP_TRY(launch_dag_flat_round(d_edges, d_cnt, cap_used, d_label, d_lab, d_changed, r, s));
-            }
-            if (prof) HIP_TRY(hipEventRecord(ctx->ev[3], s));
-            if (have_pairs)
-                HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root,
-                                            d_cnt, false, s));
-            else // no pair of this call reaches the edge list: every entry outside the fused buckets survives
+                    HIP_TRY(launch_uf_union_list(ctx->edges.as<uint2>(), d_cnt, cap_used, d_label, cap_used, s));
+                ctx->collapse_epoch += COLLAPSE_EPOCH_STEP; // (MAX_ROUNDS_PER_SYNC + 2 barriers at most per launch)
+                HIP_TRY(launch_collapse_fused(collapse_desc(), (uint32_t)ctx->n_cus, s));
+            } else { // no pair of this call reaches the edge list: every entry outside the fused buckets survives
                 HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
-            if (prof) HIP_TRY(hipEventRecord(ctx->ev[4], s));
+            }
+            if (prof) {
+                HIP_TRY(hipEventRecord(ctx->ev[3], s));
+                HIP_TRY(hipEventRecord(ctx->ev[4], s));
+            }
             if ((rc = read_control())) return rc;
             note_pair_counters();
             if (pl.seg_parts && seg_tasks_made > seg.task_cap)
@@ -1013,24 +1087,31 @@ class Pipeline {
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UF_DIRECT], 0, sizeof(unsigned long long), s));
-            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(uint32_t) * (MAX_ROUNDS_PER_SYNC + 1), s));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, CTRL_BYTES - CTRL_FLAGS_OFF, s)); // flags and sync words
             HIP_TRY(launch_iota(d_label, n, s)); // (the fused buckets' entries are finished: their labels are free)
         }
-        st.n_edges = n_edges + n_direct;
-        int rounds = have_pairs && st.n_edges ? 1 : 0;
-        for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
-        if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
-            const uint2 *d_edges = ctx->edges.as<uint2>();
-            // (comp[] is flat and lab[] is monotone: the rounds go on where the first ones stopped, now
-            // with pointer jumps -- lab[] is the identity on the entries no one-way pair has touched)
-            if ((rc = run_rounds(ctx, s, [&](uint32_t *dc, int r) {
-                     return launch_dag_round(d_edges, d_cnt, cap_used, d_label, d_lab, n, dc, r, cap_used, s);
-                 }, rounds, 4)))
-                return rc;
-            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
-            HIP_TRY(launch_map_finalize(d_label, d_lab, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt,
-                                        false, s));
-            if ((rc = read_control())) return rc;
+        const uint32_t *h_sync = ctx->h_sync();
+        st.n_edges = n_edges + n_direct + (have_pairs ? h_sync[3] : 0u);
+        int rounds = 0;
+        if (have_pairs) {
+            const bool gave_up = h_sync[1] != 0;
+            rounds = (st.n_edges ? 1 : 0) + (gave_up ? 0 : (int)h_sync[2]);
+            if (gave_up || ctx->h_changed()[MAX_ROUNDS_PER_SYNC - 1]) {
+                // flatten is idempotent and lab[] only ever falls: the phases run again, or go on, as
+                // separate launches over the state the fused kernel left
+                const CollapseDesc cd = collapse_desc();
+                if (gave_up) {
+                    // (the barrier it stopped at may have left arrivals in its counters)
+                    HIP_TRY(hipMemsetAsync(ctx->collapse_flags.p, 0, COLLAPSE_BARRIER_WORDS * sizeof(uint32_t), s));
+                    HIP_TRY(launch_collapse_flatten(cd, s)); // (lab[] starts over as the identity)
+                }
+                if ((rc = run_rounds(ctx, s, [&](uint32_t *, int r) { return launch_collapse_round(cd, r, s); },
+                                     rounds, 4)))
+                    return rc;
+                HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
+                HIP_TRY(launch_collapse_finalize(cd, s));
+                if ((rc = read_control())) return rc;
+            }
         }
         st.n_rounds = (uint32_t)rounds;
         return finish_stats();
@@ -1260,13 +1341,14 @@ void merge_stats(umi_stats &a, const umi_stats &b)
 
 int dedup_batch_single(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k, float percentage,
-                       int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root, umi_stats *stats);
+                       int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root, umi_stats *stats, int n_words = 1);
 
 // one device's share of a bucket-sharded call (runs on its own host thread)
 void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *keys, const uint64_t *nmask,
                const int32_t *freq, const uint64_t *bucket_off, int umi_len, int k, float percentage, int algo,
-               int32_t adj_max_freq, uint8_t *kept, uint32_t *root, ShardResult &res)
+               int32_t adj_max_freq, uint8_t *kept, uint32_t *root, ShardResult &res, int n_words)
 {
+    const size_t kw = 8 * (size_t)n_words; // bytes of a key (entry-major: the words of an entry are adjacent)
     memset(&res.st, 0, sizeof(res.st));
     uint64_t n_local = 0;
     sub->sh_boff.assign(1, 0);
@@ -1276,7 +1358,7 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
     }
     if (n_local == 0) return;
     // pinned staging: keys | nmask | freq in, kept | root out
-    const size_t o_keys = 0, o_nmask = o_keys + n_local * 8, o_freq = o_nmask + (nmask ? n_local * 8 : 0);
+    const size_t o_keys = 0, o_nmask = o_keys + n_local * kw, o_freq = o_nmask + (nmask ? n_local * kw : 0);
     const size_t in_bytes = o_freq + n_local * 4;
     const size_t o_kept = 0, o_root = (n_local + 15) & ~(size_t)15, out_bytes = o_root + (root ? n_local * 4 : 0);
     auto fail_here = [&](int rc) {
@@ -1297,8 +1379,8 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
     uint64_t at = 0;
     for (uint64_t b : mine) {
         const uint64_t s0 = bucket_off[b], len = bucket_off[b + 1] - s0;
-        memcpy(sub->sh_in.p + o_keys + at * 8, keys + s0, len * 8);
-        if (nmask) memcpy(sub->sh_in.p + o_nmask + at * 8, nmask + s0, len * 8);
+        memcpy(sub->sh_in.p + o_keys + at * kw, keys + s0 * (size_t)n_words, len * kw);
+        if (nmask) memcpy(sub->sh_in.p + o_nmask + at * kw, nmask + s0 * (size_t)n_words, len * kw);
         memcpy(sub->sh_in.p + o_freq + at * 4, freq + s0, len * 4);
         at += len;
     }
@@ -1308,7 +1390,7 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
                             nmask ? (const uint64_t *)(sub->sh_in.p + o_nmask) : nullptr,
                             (const int32_t *)(sub->sh_in.p + o_freq), sub->sh_boff.data(), mine.size(), umi_len, k,
                             percentage, algo, adj_max_freq, (uint8_t *)(sub->sh_out.p + o_kept),
-                            root ? (uint32_t *)(sub->sh_out.p + o_root) : nullptr, &st);
+                            root ? (uint32_t *)(sub->sh_out.p + o_root) : nullptr, &st, n_words);
     if (rc) return fail_here(rc);
     res.st = st;
     const double t2 = now();
@@ -1431,7 +1513,7 @@ int dedup_batch_split(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask,
 int dedup_batch_multi(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                       const uint64_t *bucket_off, uint64_t n_buckets, uint64_t n, int umi_len, int k,
                       float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
-                      umi_stats *stats)
+                      umi_stats *stats, int n_words = 1)
 {
     const uint32_t n_dev = (uint32_t)ctx->subs.size();
     // one bucket with more than half of the call's n_b^2: its pairs are split, not the buckets
@@ -1445,7 +1527,7 @@ int dedup_batch_multi(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask,
         max_bucket = std::max<uint64_t>(max_bucket, (uint64_t)sz);
     }
     const bool need_pairs = !(algo == UMI_ALGO_ADJACENCY && adj_max_freq < 1);
-    if (n_dev > 1 && need_pairs && max_bucket >= ctx->split_min && top * 2 > cost)
+    if (n_dev > 1 && need_pairs && max_bucket >= ctx->split_min && top * 2 > cost && n_words == 1)
         return dedup_batch_split(ctx, keys, nmask, freq, bucket_off, n_buckets, n, umi_len, k, percentage, algo,
                                  adj_max_freq, kept, root, stats);
     std::vector<uint32_t> owner;
@@ -1457,7 +1539,7 @@ int dedup_batch_multi(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask,
     for (uint32_t r = 0; r < n_dev; r++)
         pool.emplace_back([&, r] {
             run_shard(ctx->subs[r], mine[r], keys, nmask, freq, bucket_off, umi_len, k, percentage, algo, adj_max_freq,
-                      kept, root, res[r]);
+                      kept, root, res[r], n_words);
         });
     for (auto &t : pool) t.join();
     for (uint32_t r = 0; r < n_dev; r++)
@@ -1479,10 +1561,10 @@ int dedup_batch_multi(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask,
 int dedup_batch_single(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                     const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k,
                     float percentage, int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root,
-                    umi_stats *stats)
+                    umi_stats *stats, int n_words)
 {
     uint64_t n = 0;
-    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, n_words > 1 ? UMI_MAX_WIDE_UMI_LEN : UMI_MAX_UMI_LEN);
     if (rc) return rc;
     if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
     if (n == 0) {
@@ -1493,20 +1575,21 @@ int dedup_batch_single(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask
         return UMI_OK;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    if ((rc = ctx->in_keys.reserve(n * 8)) || (rc = ctx->in_freq.reserve(n * 4)) ||
+    const size_t kb = (size_t)n * 8 * (size_t)n_words;
+    if ((rc = ctx->in_keys.reserve(kb)) || (rc = ctx->in_freq.reserve(n * 4)) ||
         (rc = ctx->out_kept.reserve(n)) || (rc = ctx->out_root.reserve(n * 4)))
         return rc;
-    if (nmask && (rc = ctx->in_nmask.reserve(n * 8))) return rc;
+    if (nmask && (rc = ctx->in_nmask.reserve(kb))) return rc;
     hipStream_t s = ctx->own_stream;
-    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, kb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
-    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, n * 8, hipMemcpyHostToDevice, s));
+    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, kb, hipMemcpyHostToDevice, s));
     rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
                       nmask ? ctx->in_nmask.as<uint64_t>() : nullptr, ctx->in_freq.as<int32_t>(),
                       bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
                       algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
                       adj_max_freq, ctx->out_kept.as<uint8_t>(),
-                      root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
+                      root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats, nullptr, n_words);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
     if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
@@ -1548,6 +1631,8 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     if (err == hipSuccess)
         err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES);
     for (int i = 0; i < umi_ctx::N_EVENTS && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
+    if (err == hipSuccess && ctx->collapse_flags.reserve(COLLAPSE_BARRIER_WORDS * sizeof(uint32_t)) != UMI_OK) err = hipErrorOutOfMemory;
+    if (err == hipSuccess) err = hipMemset(ctx->collapse_flags.p, 0, COLLAPSE_BARRIER_WORDS * sizeof(uint32_t));
     if (err != hipSuccess) {
         umi_ctx_destroy(ctx);
         return fail(UMI_ERR_HIP, "context setup failed: %s", hipGetErrorString(err));
@@ -1568,7 +1653,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     ctx->sh_in.release();
     ctx->sh_out.release();
     DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->plan_tables, &ctx->fkey_sorted, &ctx->perm,
-                      &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_chunk_sums, &ctx->seg_tasks,
+                      &ctx->collapse_flags, &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_tasks,
                       &ctx->seg_sub_rec, &ctx->seg_priv_edges, &ctx->seg_priv_dist, &ctx->seg_priv_cnt,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
@@ -1580,7 +1665,8 @@ void umi_ctx_destroy(umi_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_boff) (void)hipHostFree(ctx->h_boff);
     ctx->h_tasks.release();
-    ctx->h_plan.release();
+    ctx->h_plan_alt[0].release();
+    ctx->h_plan_alt[1].release();
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     for (int i = 0; i < umi_ctx::N_EVENTS; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -1659,6 +1745,9 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->seg_min = (uint32_t)value;
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
+    } else if (!strcmp(name, "fused_blocks")) {
+        if (value < 1 || value > 16) return fail(UMI_ERR_ARG, "fused_blocks must be in 1..16");
+        ctx->fused_blocks = (uint32_t)value;
     } else if (!strcmp(name, "fused_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
         ctx->fused_max = (uint32_t)std::min<int64_t>(value, FUSED_MAX);
@@ -1799,7 +1888,11 @@ int umi_dedup_batch_wide_device(umi_ctx *ctx, const uint64_t *d_keys, const uint
                                 int k, float percentage, int algo, int32_t adj_max_freq, uint8_t *d_kept,
                                 uint32_t *d_root, void *hip_stream, umi_stats *stats)
 {
-    if (ctx && !ctx->subs.empty()) ctx = ctx->subs[0]; // (multi-word keys run on the first device)
+    if (ctx && !ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
     uint64_t n = 0;
     int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, UMI_MAX_WIDE_UMI_LEN);
     if (rc) return rc;
@@ -1821,15 +1914,17 @@ int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nma
                          const uint64_t *bucket_off, uint64_t n_buckets, int umi_len, int k, float percentage,
                          int algo, int32_t adj_max_freq, uint8_t *kept, uint32_t *root, umi_stats *stats)
 {
-    if (ctx && !ctx->subs.empty()) ctx = ctx->subs[0];
-    uint64_t n = 0;
-    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, UMI_MAX_WIDE_UMI_LEN);
-    if (rc) return rc;
     if (n_words == 1) // one word: the ordinary call
         return umi_dedup_batch(ctx, keys, nmask, freq, bucket_off, n_buckets, umi_len, k, percentage, algo,
                                adj_max_freq, kept, root, stats);
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n, UMI_MAX_WIDE_UMI_LEN);
+    if (rc) return rc;
     if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
     if (n && (!keys || !freq || !kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    for (uint64_t b = 0; b < n_buckets; b++)
+        if (bucket_off[b + 1] < bucket_off[b])
+            return fail(UMI_ERR_ARG, "bucket_off not monotone at bucket %llu", (unsigned long long)b);
     if (n == 0) {
         if (stats) {
             memset(stats, 0, sizeof(*stats));
@@ -1837,25 +1932,12 @@ int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nma
         }
         return UMI_OK;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t kb = (size_t)n * 8 * (size_t)n_words;
-    if ((rc = ctx->in_keys.reserve(kb)) || (rc = ctx->in_freq.reserve(n * 4)) || (rc = ctx->out_kept.reserve(n)) ||
-        (rc = ctx->out_root.reserve(n * 4)))
-        return rc;
-    if (nmask && (rc = ctx->in_nmask.reserve(kb))) return rc;
-    hipStream_t s = ctx->own_stream;
-    HIP_TRY(hipMemcpyAsync(ctx->in_keys.p, keys, kb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_freq.p, freq, n * 4, hipMemcpyHostToDevice, s));
-    if (nmask) HIP_TRY(hipMemcpyAsync(ctx->in_nmask.p, nmask, kb, hipMemcpyHostToDevice, s));
-    rc = umi_dedup_batch_wide_device(ctx, ctx->in_keys.as<uint64_t>(), nmask ? ctx->in_nmask.as<uint64_t>() : nullptr,
-                                     n_words, ctx->in_freq.as<int32_t>(), bucket_off, n_buckets, umi_len, k, percentage,
-                                     algo, adj_max_freq, ctx->out_kept.as<uint8_t>(),
-                                     root ? ctx->out_root.as<uint32_t>() : nullptr, s, stats);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(kept, ctx->out_kept.p, n, hipMemcpyDeviceToHost, s));
-    if (root) HIP_TRY(hipMemcpyAsync(root, ctx->out_root.p, n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return UMI_OK;
+    // a multi-device context shards the buckets over its devices exactly as for one-word keys
+    if (!ctx->subs.empty() && ctx->subs.size() > 1)
+        return dedup_batch_multi(ctx, keys, nmask, freq, bucket_off, n_buckets, n, umi_len, k, percentage, algo,
+                                 adj_max_freq, kept, root, stats, n_words);
+    return dedup_batch_single(ctx->subs.empty() ? ctx : ctx->subs[0], keys, nmask, freq, bucket_off, n_buckets, umi_len, k,
+                              percentage, algo, adj_max_freq, kept, root, stats, n_words);
 }
 
 int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits, const uint8_t *d_umi_ascii,
@@ -2067,13 +2149,20 @@ extern "C" {
 int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                  uint32_t n, int umi_len, int max_edits, umi_data **out)
 {
+    return umi_data_new_wide(ctx, keys, nmask, 1, freq, n, umi_len, max_edits, out);
+}
+
+int umi_data_new_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                      uint32_t n, int umi_len, int max_edits, umi_data **out)
+{
     if (!out) return fail(UMI_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
     if (!ctx->subs.empty()) ctx = ctx->subs[0]; // one bucket's store lives on one device
     if (n && (!keys || !freq)) return fail(UMI_ERR_ARG, "keys/freq is NULL");
-    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN)
-        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (umi_len < 1 || umi_len > UMI_MAX_WIDE_UMI_LEN)
+        return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_WIDE_UMI_LEN);
+    if (n_words != (3 * umi_len + 63) / 64) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", (3 * umi_len + 63) / 64, umi_len);
     if (max_edits < 0) return fail(UMI_ERR_ARG, "max_edits must be >= 0");
     if (n >= 0x7FFFFFF0u) // same index space as the batched calls (bit 31 of an edge endpoint is a flag)
         return fail(UMI_ERR_ARG, "%u entries exceed the 31-bit index space of one store", n);
@@ -2088,18 +2177,19 @@ int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, cons
     if (n >= 2) {
         int rc;
         HIP_TRY(hipSetDevice(ctx->device));
-        if ((rc = ctx->in_keys.reserve((size_t)n * 8)) || (rc = ctx->in_freq.reserve((size_t)n * 4)) ||
-            (nmask && (rc = ctx->in_nmask.reserve((size_t)n * 8))))
+        const size_t kb = (size_t)n * 8 * (size_t)n_words;
+        if ((rc = ctx->in_keys.reserve(kb)) || (rc = ctx->in_freq.reserve((size_t)n * 4)) ||
+            (nmask && (rc = ctx->in_nmask.reserve(kb))))
             return rc;
         hipStream_t s = ctx->own_stream;
         // the neighbour build ignores freq and order; feed ones so that prep's
         // contract check (rank order) does not apply to an unordered map
         std::vector<int32_t> ones(n, 1);
-        hipError_t e = hipMemcpyAsync(ctx->in_keys.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, s);
+        hipError_t e = hipMemcpyAsync(ctx->in_keys.p, keys, kb, hipMemcpyHostToDevice, s);
         if (e == hipSuccess)
             e = hipMemcpyAsync(ctx->in_freq.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess && nmask)
-            e = hipMemcpyAsync(ctx->in_nmask.p, nmask, (size_t)n * 8, hipMemcpyHostToDevice, s);
+            e = hipMemcpyAsync(ctx->in_nmask.p, nmask, kb, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s); // `ones` must outlive the copy
         if (e != hipSuccess) return fail(UMI_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         const uint64_t boff[2] = {0, n};
@@ -2107,7 +2197,7 @@ int umi_data_new(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nmask, cons
         rc = run_pipeline(ctx, ctx->in_keys.as<uint64_t>(),
                           nmask ? ctx->in_nmask.as<uint64_t>() : nullptr,
                           ctx->in_freq.as<int32_t>(), boff, 1, n, umi_len, max_edits, 0.0f,
-                          MODE_NEIGHBOURS, 0, nullptr, nullptr, s, &st);
+                          MODE_NEIGHBOURS, 0, nullptr, nullptr, s, &st, nullptr, n_words);
         if (rc) return rc;
         const size_t E = (size_t)st.n_edges;
         std::vector<uint2> pairs(E);

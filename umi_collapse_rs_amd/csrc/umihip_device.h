@@ -35,11 +35,26 @@ template <> __device__ __forceinline__ uint64_t pad_col<uint64_t>() { return 0xF
 __device__ __forceinline__ int32_t threshold_of(float percentage, int32_t freq)
 {
     // freq + 1 wraps in a release build of the reference (Cargo.toml:16-19)
-    float prod = __fmul_rn(percentage, (float)(int32_t)((uint32_t)freq + 1u));
-    if (prod != prod) return 0;
-    if (prod >= 2147483648.0f) return 2147483647;
-    if (prod <= -2147483648.0f) return (-2147483647 - 1);
-    return (int32_t)prod;
+    const float prod = __fmul_rn(percentage, (float)(int32_t)((uint32_t)freq + 1u));
+    // v_cvt_i32_f32 is Rust's `as i32`: truncation toward zero, out-of-range values (infinities
+    // included) saturate, NaN gives 0 -- one instruction where the C cast needs three range tests
+    int32_t t;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(t) : "v"(prod));
+    return t;
+}
+
+// Bases 21 .. umi_len - 1 of a key of several words that hold the N code (100): a caller that passes
+// no nmask promises there is none (the first word's 21 bases are looked at with the filter key).
+__device__ __forceinline__ unsigned int wide_n_codes(const uint64_t *__restrict__ key, int key_words, int umi_len)
+{
+    unsigned int bad = 0;
+    for (int b = 21; b < umi_len; b++) {
+        const int bit = 3 * b, w = bit >> 6, sh = bit & 63;
+        uint64_t c = key[w] >> sh;
+        if (sh > 61 && w + 1 < key_words) c |= key[w + 1] << (64 - sh); // a straddling base
+        bad += (c & 7ull) == 4ull ? 1u : 0u;
+    }
+    return bad;
 }
 
 // sum `cnt` over the block (256 threads) and add it to *dst with one atomic

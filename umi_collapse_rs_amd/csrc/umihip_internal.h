@@ -46,7 +46,13 @@ enum Counter : int {
 // The flags of the collapse rounds ("round r changed a label") sit behind the counters in the
 // same device block, so that one memset clears and one copy reads everything the host looks at.
 constexpr int MAX_ROUNDS_PER_SYNC = 16; // rounds enqueued between two host checks
-constexpr size_t CTRL_BYTES = CNT_COUNT * sizeof(unsigned long long) + (MAX_ROUNDS_PER_SYNC + 1) * sizeof(uint32_t);
+// ... and behind the flags the words of the fused collapse kernel: [0] barrier arrivals, [1] "gave
+// up" (a barrier was not passed in time: the host runs the phases as separate launches), [2] one-way
+// rounds it ran, [3] one-way pairs it found in the pair kernel's private slots
+constexpr int COLLAPSE_SYNC_WORDS = 4;
+constexpr size_t CTRL_FLAGS_OFF = CNT_COUNT * sizeof(unsigned long long);
+constexpr size_t CTRL_SYNC_OFF = CTRL_FLAGS_OFF + (MAX_ROUNDS_PER_SYNC + 1) * sizeof(uint32_t);
+constexpr size_t CTRL_BYTES = (CTRL_SYNC_OFF + COLLAPSE_SYNC_WORDS * sizeof(uint32_t) + 255) & ~(size_t)255; // (one fill kernel: a whole number of 16-byte words)
 
 // Bit-sliced kernel: one block works on rows [bucket_start + 32*group0, ...) of one
 // bucket (256*G or 64*G groups of 32 rows, see BS_* below) against columns [col0, col1).
@@ -201,14 +207,16 @@ constexpr int COL_TILE = 1024; // column keys staged in LDS per step
 
 // segs/bin_cnt (may be null): entries of ranges with a segment also count themselves into the
 // bins of their n_seg_parts parts
-// skip_seg: the ranges of segments are the count kernel's (SegArgs::prep_keys); entries_too false:
-// only the rises at bucket starts (every range is a segment's)
+// skip_seg: the ranges of segments are the count kernel's (SegArgs::prep_keys), which also tells a
+// rise at its bucket's start from one inside (seg_from: the smallest segment); entries_too false:
+// every range is a segment's, nothing to launch
 hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                        const uint64_t *bucket_off, uint64_t n_buckets, const RangeTask *ranges,
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
-                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg = false, bool entries_too = true);
+                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg = false, bool entries_too = true,
+                       uint32_t seg_from = 0xFFFFFFFFu, int key_words = 1, int full_umi_len = 0);
 
 // ---- segment index (umihip_seg.hip) ----
 struct SegArgs {
@@ -218,7 +226,8 @@ struct SegArgs {
     int n_parts;            // k + 1
     uint32_t *bin_cnt;      // [n_bins] entries per bin (prep); reused as the scatter cursor
     uint32_t *bin_start;    // [n_bins] first position of the bin in the sub-bucket arrays
-    uint2 *chunk_sums;      // [n_chunks] scratch of the scan: (entries, tasks) per chunk
+    unsigned long long *scan_state; // [1 + n_chunks] the scan's ticket counter and its chunks' status words
+                                    // (zeroed with bin_cnt: they sit behind it in one block)
     SegTask *tasks;         // [task_cap]
     uint32_t task_cap;
     void *sub_rec;          // [n_parts * M] entries in sub-bucket order: SegRec32 / SegRec64, one
@@ -247,7 +256,9 @@ struct SegArgs {
     uint32_t *prep_label;
     float prep_percentage;
     unsigned long long *prep_counters;
-    int umi_len;
+    int umi_len;            // (keys of several words: 21, the bases of the first word the filter keys hold)
+    int key_words;          // words per key in prep_keys / prep_nmask and in the pair kernel's exact check
+    int full_umi_len;       // ... and the whole length of such keys (the N-code check of the entry pass)
     uint32_t use_ckey; // 32-bit keys: the pair kernel compares the records' compare keys (every part of
                        // every segment leaves at most 10 bases outside its bins)
 };
@@ -264,13 +275,8 @@ hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, flo
 hipError_t launch_seg_edge_append(const PairArgs &a, const SegArgs &g, uint32_t n_blocks, hipStream_t s);
 
 // ---- multi-word keys (umihip_wide.hip): umi_len 22..85, n_words = 2..4 words per key, entry-major
-hipError_t launch_wide_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                            const RangeTask *ranges, uint32_t n_ranges, int n_words, int umi_len, float percentage,
-                            int32_t *thr, uint32_t *label, unsigned long long *counters, hipStream_t s);
 // a.tasks: rows [row0, row0 + 64) x columns [col0, col1) of one bucket; exact distance from all words
 hipError_t launch_wide_pairs(const PairArgs &a, uint32_t n_tasks, int n_words, hipStream_t s);
-hipError_t launch_bucket_rise(const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
-                              unsigned long long *counters, hipStream_t s);
 
 // ---- read staging on the device (umihip_stage.hip) ----
 size_t stage_workspace_bytes(uint32_t n_reads);
@@ -294,20 +300,40 @@ hipError_t launch_uf_components(const uint2 *edges, const unsigned long long *co
 // rounds along the listed one-way pairs without pointer jumps.
 hipError_t launch_uf_union_list(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
                                 uint32_t *parent, uint32_t n_edges_hint, hipStream_t s);
-hipError_t launch_dag_flat_round(const uint2 *edges, const unsigned long long *counters, uint32_t edge_cap,
-                                 const uint32_t *comp, uint32_t *lab, uint32_t *changed, int round,
-                                 hipStream_t s);
-// comp[v] = root of v, in place, and lab[v] = v for all n entries
-hipError_t launch_uf_flatten(uint32_t *parent, uint32_t *lab, uint32_t n, hipStream_t s);
-// label = lab[comp[v]] for the entries of ranges (null: all n), kept / root / survivor count:
-// map_labels + finalize in one pass
+// The collapse behind the pair kernels of the batched directional path: what it works on ...
+struct CollapseDesc {
+    uint32_t *parent, *lab;  // label[] (the union-find forest of the symmetric pairs) and lab[]
+    const uint2 *edges;      // the list
+    uint32_t edge_cap;
+    const uint2 *priv_edges; // the pair kernel's private slots (null: everything is in the list)
+    const uint32_t *priv_cnt;
+    uint32_t n_slots;
+    const RangeTask *ranges; // entries the fused small-bucket kernel left (null: all n)
+    uint32_t n_ranges, n;
+    uint8_t *kept;
+    uint32_t *root;
+    unsigned long long *counters;
+    uint32_t *changed, *sync; // the flags and sync words of the control block
+    uint32_t *flags;          // [COLLAPSE_BARRIER_WORDS] the fused kernel's barrier: a flag word per block, then the arrival
+                              // counters (a line each; zero at creation, left zero by every barrier that was passed)
+    uint32_t epoch;           // grows by COLLAPSE_EPOCH_STEP per launch: a barrier's number is epoch + its index
+};
+constexpr uint32_t COLLAPSE_MAX_GRID = 2048, COLLAPSE_EPOCH_STEP = 64;
+constexpr uint32_t COLLAPSE_GROUP_WORDS = COLLAPSE_MAX_GRID / 32; // a counter per group of 32 blocks
+constexpr uint32_t COLLAPSE_LINE_WORDS = 16;                      // one 64-byte line per flag and counter
+constexpr size_t COLLAPSE_BARRIER_WORDS = (size_t)(COLLAPSE_MAX_GRID + COLLAPSE_GROUP_WORDS + 1) * COLLAPSE_LINE_WORDS;
+// ... in one launch (flatten, one-way rounds until one is quiet, kept / root / survivor count; grid
+// barriers in between) ...
+hipError_t launch_collapse_fused(const CollapseDesc &d, uint32_t n_cus, hipStream_t s);
+// bytes (a multiple of 8) of the control block to its pinned, device-visible host mirror
+hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes, hipStream_t s);
+// ... and phase by phase: comp[v] = root of v in place and lab[v] = v; round `round` along the
+// one-way pairs (a no-op once round - 1 was quiet); label = lab[comp[v]], kept, root, survivors
+hipError_t launch_collapse_flatten(const CollapseDesc &d, hipStream_t s);
+hipError_t launch_collapse_round(const CollapseDesc &d, int round, hipStream_t s);
+hipError_t launch_collapse_finalize(const CollapseDesc &d, hipStream_t s);
 // bits[i / 8] bit (i % 8) = kept[i] != 0, for i < n (ceil(n / 8) bytes written)
 hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipStream_t s);
-// find: comp[] is a forest (climb to the root), else flat
-hipError_t launch_map_finalize(const uint32_t *comp, const uint32_t *lab, const RangeTask *ranges,
-                               uint32_t n_ranges, uint32_t n, uint8_t *kept, uint32_t *root,
-                               unsigned long long *counters, bool find, hipStream_t s);
-
 
 hipError_t launch_pairs(const PairArgs &a, uint32_t n_tasks, bool big, bool key32, hipStream_t s);
 
@@ -368,7 +394,12 @@ hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, con
                                 float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
                                 uint32_t fused_max, uint32_t n_entries, uint32_t *label, uint8_t *kept, uint32_t *root,
                                 int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
-                                unsigned long long *counters, hipStream_t s);
+                                unsigned long long *counters, uint32_t max_blocks, hipStream_t s);
+
+hipError_t launch_small_buckets_wide(const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                                     float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
+                                     uint32_t fused_max, uint32_t n_entries, uint8_t *kept, uint32_t *root, int k,
+                                     int umi_len, unsigned long long *counters, uint32_t max_blocks, hipStream_t s);
 
 // one label-propagation round (hook over edges + pointer jump); round r is a
 // no-op on the device when round r-1 changed nothing.

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
                                                    uint32_t *__restrict__ lab,
                                                    unsigned long long *__restrict__ counters,
                                                    const SegDesc *__restrict__ segs, int n_seg_parts,
-                                                   uint32_t *__restrict__ bin_cnt, int skip_seg)
+                                                   uint32_t *__restrict__ bin_cnt, int skip_seg, int key_words,
+                                                   int full_umi_len)
 {
     if (skip_seg && ranges && ranges[blockIdx.x].seg != SEG_NONE) return; // the count kernel's entries
     unsigned int bad = 0, rises = 0;
@@ -60,15 +61,17 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
     const uint32_t seg = ranges && segs ? ranges[blockIdx.x].seg : SEG_NONE;
     const SegDesc *__restrict__ sd = seg != SEG_NONE ? segs + seg : nullptr;
     for_entries(ranges, n, [&](uint32_t i) {
-        const uint64_t key = keys[i];
-        const uint64_t nm = nmask ? nmask[i] : 0ull;
+        // (keys of key_words > 1 words, umi_len 22..85: the filter key is made of the first word's 21
+        // bases -- umi_len is 21 here -- and every filter hit is decided on all words)
+        const uint64_t key = keys[(size_t)i * key_words];
+        const uint64_t nm = nmask ? nmask[(size_t)i * key_words] : 0ull;
         const int32_t f = freq[i];
         thr[i] = threshold_of(percentage, f);
         label[i] = i;
         if (lab) lab[i] = i; // (the one-way rounds' labels: smallest set that reaches this one)
         // filter key: N (100, masked by n_bits) folded onto A (000) so that the
         // filter distance never exceeds the exact one.
-        const uint64_t k3 = key & ~nm;
+        const uint64_t k3 = key & ~nm & (umi_len >= 21 ? 0x7FFFFFFFFFFFFFFFull : ((1ull << (3 * umi_len)) - 1ull));
         uint32_t fk = 0;
         if (key32) {
             for (int b = 0; b < umi_len; b++) fk |= (uint32_t)((k3 >> (3 * b)) & 3ull) << (2 * b);
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
         // filter key for the key.  A folded key has no base with bit 2 set and bits 0, 1 clear.
         const uint64_t b2 = k3 & 0x4924924924924924ull;
         bad += (b2 & ~((k3 << 1) | (k3 << 2))) != 0 ? 1u : 0u;
+        if (key_words > 1 && !nmask) bad += wide_n_codes(keys + (size_t)i * key_words, key_words, full_umi_len);
         rises += (i > 0 && f > freq[i - 1]) ? 1u : 0u;
     });
     block_count_add(bad, &counters[CNT_ERROR]);
@@ -103,14 +107,17 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint64_t *__restrict__ 
 __global__ __launch_bounds__(256) void bucket_rise_kernel(const int32_t *__restrict__ freq,
                                                           const uint64_t *__restrict__ bucket_off,
                                                           uint64_t n_buckets, uint32_t fused_max,
-                                                          uint32_t n_entries,
+                                                          uint32_t skip_from, uint32_t n_entries,
                                                           unsigned long long *__restrict__ counters)
 {
+    // (buckets of skip_from entries and more are segments whose count kernel tells a rise at the
+    // bucket's start from one inside it by itself)
     unsigned int rises = 0;
     for (uint64_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets;
          b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t s = bucket_off[b], e = bucket_off[b + 1];
-        if (s > 0 && s < e && e <= (uint64_t)n_entries && e - s > fused_max) rises += freq[s] > freq[s - 1] ? 1u : 0u;
+        if (s > 0 && s < e && e <= (uint64_t)n_entries && e - s > fused_max && e - s < skip_from)
+            rises += freq[s] > freq[s - 1] ? 1u : 0u;
     }
     block_count_add(rises, &counters[CNT_START_RISES]);
 }
@@ -255,7 +262,7 @@ __device__ __forceinline__ unsigned int fused_write_out(uint32_t start, int n, c
         const int row = lane + 64 * s;
         if (row < n) {
             const bool kp = MODE == MODE_DIRECTIONAL ? lab[s] == (uint32_t)row : alive[s] != 0u;
-            label[start + row] = start + lab[s];
+            if (label) label[start + row] = start + lab[s];
             kept[start + row] = kp ? 1 : 0;
             if (root) root[start + row] = (MODE != MODE_DIRECTIONAL && kp) ? start + row : start + lab[s];
             n_kept += kp ? 1u : 0u;
@@ -622,11 +629,330 @@ __device__ __forceinline__ FusedCounts small_bucket_body_bs(const uint64_t *__re
     return out;
 }
 
+// ---- the directional body again, counted instruction by instruction ------------------------------
+// A batch of small positions is this kernel and nothing else, and the kernel is bound by VALU issue
+// (SQ counters: ~580 wave instructions per position of ~60 UMIs, 8 waves per SIMD): what it saves
+// it saves in instructions.  Same algorithm as small_bucket_body_bs, with
+//  * the rows' code bits taken four bases at a time out of one 12-bit window (one 64-bit shift per
+//    four bases instead of one per base);
+//  * q[row] = how many sources may remove the row (thr[j] >= freq[row]: a prefix, thresholds being in
+//    rank order) and q'[j] = the first row source j may remove (freq[r] <= thr[j]: a suffix) found
+//    per DISTINCT freq of the bucket -- a handful -- with two ballots each, instead of a seven-step
+//    binary search over ds_bpermute per row;
+//  * the sources that have an out-edge at all as ONE ballot: distances are symmetric, so lane j's own
+//    hit mask, cut to the rows from q'[j] on, says whether j removes anything (was: an OR-reduction
+//    of the in-edge masks over the wave, six ds_bpermute steps per half);
+//  * neighbour values through DPP (wave_shr) instead of ds_bpermute; label[] not written (nothing
+//    reads it for a finished bucket).
+// Thresholds out of rank order (percentage < 0, freq + 1 wrapped) go to small_bucket_body_bs.
+__device__ __forceinline__ int32_t lane_above(int32_t v, int32_t first)
+{ // the value of the lane before (lane 0: `first`): DPP wave_shr:1, one instruction
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t low_bits(int nb)
+{ // nb <= 0: none, nb >= 32: all
+    return nb >= 32 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+}
+__device__ __forceinline__ unsigned long long low_bits64(int nb)
+{
+    return nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
+}
+
+// W = words per key (1: umi_len <= 21; 2..4: up to 85 bases, keys entry-major [i * W + w], the
+// distance word by word as src/utils/bitset.rs:77-91 has it).
+// twelve bits of a W-word string from bit 3 * g on (g wave-uniform); a window may run over a word's end
+template <int W> __device__ __forceinline__ uint32_t window12(const uint64_t (&f)[W], int g)
+{
+    if (W == 1) return (uint32_t)(f[0] >> (3 * g));
+    const int bit = 3 * g, wi = bit >> 6, sh = bit & 63;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++)
+        if (wi == w) {
+            lo = f[w];
+            hi = w + 1 < W ? f[w + 1] : 0ull;
+        }
+    uint64_t v = lo >> sh;
+    if (sh > 52) v |= hi << (64 - sh);
+    return (uint32_t)v;
+}
+
+template <int RL, bool HAS_N, int K, int W>
+__device__ __forceinline__ FusedCounts small_bucket_body_dir(const uint64_t *__restrict__ keys,
+                                                             const uint64_t *__restrict__ nmask,
+                                                             const int32_t *__restrict__ freq,
+                                                             float percentage, uint32_t start, int n,
+                                                             int umi_len, uint32_t *__restrict__ label,
+                                                             uint8_t *__restrict__ kept,
+                                                             uint32_t *__restrict__ root)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr int H = 2 * RL;
+    uint64_t key[RL][W], nm[RL][W], fold[RL][W];
+    int32_t fr[RL], th[RL];
+    unsigned long long vmask[RL]; // lanes whose row of slot s exists (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int r = lane + 64 * s;
+        const bool in_range = r < n;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            key[s][w] = in_range ? keys[(size_t)(start + r) * W + w] : 0ull;
+            nm[s][w] = (HAS_N && in_range) ? nmask[(size_t)(start + r) * W + w] : 0ull;
+            fold[s][w] = key[s][w] & ~nm[s][w]; // N folded onto A: the sliced distance never exceeds the exact one
+        }
+        fr[s] = in_range ? freq[start + r] : 0x7FFFFFFF;
+        th[s] = in_range ? threshold_of(percentage, fr[s]) : (-0x7FFFFFFF - 1);
+        const int left = n - 64 * s;
+        vmask[s] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+    }
+    // thresholds in rank order?  (and the contract: freq >= 1, not rising)
+    bool rise_th = false;
+    unsigned int bad = 0;
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int32_t th_first = s == 0 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(th[0], 63);
+        const int32_t fr_first = s == 0 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(fr[0], 63);
+        rise_th |= th[s] > lane_above(th[s], th_first);
+        const bool row = lane + 64 * s < n;
+        bad += (row && fr[s] < 1 ? 1u : 0u) + (row && fr[s] > lane_above(fr[s], fr_first) ? 1u : 0u);
+    }
+    const bool monotone = !__any(rise_th);
+    // cnt[s][h][l]: columns of half h at which row (lane + 64 s) has more than l mismatches so far
+    uint32_t cnt[RL][H][K + 1];
+#pragma unroll
+    for (int s = 0; s < RL; s++)
+#pragma unroll
+        for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int l = 0; l <= K; l++) cnt[s][h][l] = 0u;
+    uint32_t n_code[RL]; // (keys of several words without nmask: a base that holds the N code, 100)
+#pragma unroll
+    for (int s = 0; s < RL; s++) n_code[s] = 0u;
+    auto one_base = [&](const uint32_t (&w)[RL], int j) { // base j (a constant) of the window
+        uint32_t r0[RL], r1[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            r0[s] = (uint32_t)__builtin_amdgcn_sbfe((int)w[s], 3u * (uint32_t)j, 1u);
+            r1[s] = (uint32_t)__builtin_amdgcn_sbfe((int)w[s], 3u * (uint32_t)j + 1u, 1u);
+            if (W > 1 && !HAS_N) n_code[s] |= (w[s] >> (3 * j + 2)) & ~r0[s] & ~r1[s] & 1u;
+        }
+#pragma unroll
+        for (int c = 0; c < RL; c++) {
+            const unsigned long long p0 = __builtin_amdgcn_uicmp(r0[c], 0u, 33 /* ICMP_NE */);
+            const unsigned long long p1 = __builtin_amdgcn_uicmp(r1[c], 0u, 33);
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t c0 = (uint32_t)(p0 >> (32 * hh)), c1 = (uint32_t)(p1 >> (32 * hh));
+#pragma unroll
+                for (int s = 0; s < RL; s++) {
+                    const uint32_t m = BITOP3(c0 ^ r0[s], c1, r1[s], TT_A | (TT_B ^ TT_C));
+#pragma unroll
+                    for (int l = K; l >= 1; l--)
+                        cnt[s][2 * c + hh][l] = BITOP3(cnt[s][2 * c + hh][l], cnt[s][2 * c + hh][l - 1], m,
+                                                       TT_A | (TT_B & TT_C));
+                    cnt[s][2 * c + hh][0] |= m;
+                }
+            }
+        }
+    };
+    int g = 0;
+    for (; g + 4 <= umi_len; g += 4) { // four bases of every row: 12 bits
+        uint32_t w[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) w[s] = window12<W>(fold[s], g);
+        one_base(w, 0);
+        one_base(w, 1);
+        one_base(w, 2);
+        one_base(w, 3);
+    }
+    for (; g < umi_len; g++) {
+        uint32_t w[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) w[s] = window12<W>(fold[s], g);
+        one_base(w, 0);
+    }
+    // hits[s][h]: columns of half h within K of row (lane + 64 s), the row itself included
+    uint32_t hits[RL][H];
+#pragma unroll
+    for (int s = 0; s < RL; s++)
+#pragma unroll
+        for (int h = 0; h < H; h++) hits[s][h] = ~cnt[s][h][K] & low_bits(n - 32 * h);
+    if (HAS_N) { // exact re-check of the hits (bitset.rs:77-91), column values through ds_bpermute
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                uint32_t todo = hits[s][h];
+                while (__any(todo != 0)) { // all lanes stay in the loop: bpermute needs its sources
+                    const int jj = todo ? __builtin_ctz(todo) : 0;
+                    const int src = 32 * (h & 1) + jj;
+                    int bcx = 0;
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        const uint64_t kj = ((uint64_t)(uint32_t)__shfl((int)(key[h >> 1][w] >> 32), src) << 32) |
+                                            (uint32_t)__shfl((int)key[h >> 1][w], src);
+                        const uint64_t nj = ((uint64_t)(uint32_t)__shfl((int)(nm[h >> 1][w] >> 32), src) << 32) |
+                                            (uint32_t)__shfl((int)nm[h >> 1][w], src);
+                        const uint64_t x = nm[s][w] ^ nj;
+                        bcx += __builtin_popcountll(x | (key[s][w] ^ kj)) - __builtin_popcountll(x) / 3;
+                    }
+                    if (todo) {
+                        if (bcx > 2 * K + 1) hits[s][h] &= ~(1u << jj);
+                        todo &= todo - 1;
+                    }
+                }
+            }
+    }
+    // in-edges of the rows, and the sources that have an out-edge at all; columns 64 at a time
+    unsigned long long in[RL][RL], act64[RL];
+    if (monotone) {
+        // q / q' per distinct freq of the bucket (a wave-uniform loop; the lanes of one freq leave together)
+        int q[RL], qp[RL];
+        unsigned long long todo[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            q[s] = 0;
+            qp[s] = 0;
+            todo[s] = vmask[s];
+        }
+        for (;;) {
+            int32_t v, tv;
+            if (todo[0]) {
+                const int l = __builtin_ctzll(todo[0]);
+                v = __builtin_amdgcn_readlane(fr[0], l);
+                tv = __builtin_amdgcn_readlane(th[0], l);
+            } else if (RL == 2 && todo[RL - 1]) {
+                const int l = __builtin_ctzll(todo[RL - 1]);
+                v = __builtin_amdgcn_readlane(fr[RL - 1], l);
+                tv = __builtin_amdgcn_readlane(th[RL - 1], l);
+            } else {
+                break;
+            }
+            int n_src = 0, n_above = 0;
+#pragma unroll
+            for (int s = 0; s < RL; s++) {
+                n_src += __builtin_popcountll(__ballot(th[s] >= v) & vmask[s]);   // sources that may remove a row of freq v
+                n_above += __builtin_popcountll(__ballot(fr[s] > tv) & vmask[s]); // rows a source of this freq may not remove
+            }
+#pragma unroll
+            for (int s = 0; s < RL; s++) {
+                const bool mine = fr[s] == v;
+                q[s] = mine ? n_src : q[s];
+                qp[s] = mine ? n_above : qp[s];
+                todo[s] &= ~__ballot(mine);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            unsigned long long out_any = 0;
+#pragma unroll
+            for (int c = 0; c < RL; c++) {
+                const unsigned long long hit = ((unsigned long long)hits[s][2 * c + 1] << 32) | hits[s][2 * c];
+                const unsigned long long h_ns = s == c ? hit & ~(1ull << lane) : hit; // not the row itself
+                in[s][c] = h_ns & low_bits64(q[s] - 64 * c);
+                out_any |= h_ns & ~low_bits64(qp[s] - 64 * c);
+            }
+            act64[s] = __ballot(out_any != 0ull) & vmask[s];
+        }
+    } else {
+        // thresholds out of rank order (percentage < 0, freq + 1 wrapped): every (row, source) pair is
+        // tested by itself, a source per trip (rare, so it only has to be right)
+        unsigned long long may[RL][RL], gives[RL][RL]; // may[s][c]: sources of slot c that pass row s's freq test;
+                                                       // gives[s][c]: rows of slot c the source in slot s may remove
+#pragma unroll
+        for (int s = 0; s < RL; s++)
+#pragma unroll
+            for (int c = 0; c < RL; c++) may[s][c] = gives[s][c] = 0ull;
+#pragma unroll
+        for (int c = 0; c < RL; c++) {
+            const int jn = min(64, n - 64 * c);
+            for (int j = 0; j < jn; j++) {
+                const int32_t thj = __builtin_amdgcn_readlane(th[c], j), frj = __builtin_amdgcn_readlane(fr[c], j);
+#pragma unroll
+                for (int s = 0; s < RL; s++) {
+                    may[s][c] |= fr[s] <= thj ? 1ull << j : 0ull;   // naive.rs:31 with max_freq = threshold(source j)
+                    gives[s][c] |= frj <= th[s] ? 1ull << j : 0ull; // ... and this lane as the source, row j
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RL; s++) {
+            unsigned long long out_any = 0;
+#pragma unroll
+            for (int c = 0; c < RL; c++) {
+                const unsigned long long hit = ((unsigned long long)hits[s][2 * c + 1] << 32) | hits[s][2 * c];
+                const unsigned long long h_ns = s == c ? hit & ~(1ull << lane) : hit;
+                in[s][c] = h_ns & may[s][c];
+                out_any |= h_ns & gives[s][c];
+            }
+            act64[s] = __ballot(out_any != 0ull) & vmask[s];
+        }
+    }
+    bool back = false;
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int row = lane + 64 * s;
+#pragma unroll
+        for (int c = 0; c < RL; c++) {
+            if (row >= n) in[s][c] = 0ull;
+            // an in-edge from a source ranked behind the row: one sweep is then not the fixed point
+            back |= (in[s][c] & ~low_bits64(row - 64 * c + 1)) != 0ull;
+        }
+    }
+    uint32_t lab[RL];
+#pragma unroll
+    for (int s = 0; s < RL; s++) lab[s] = (uint32_t)(lane + 64 * s);
+    const bool iterate = __any(back);
+    bool changed;
+    do { // Gauss-Seidel sweeps in rank order over the active sources until no label moves
+        uint32_t before[RL];
+#pragma unroll
+        for (int s = 0; s < RL; s++) before[s] = lab[s];
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            uint32_t t = (uint32_t)(act64[h >> 1] >> (32 * (h & 1)));
+            while (t) {
+                const int jj = __builtin_ctz(t);
+                t &= t - 1;
+                const uint32_t lj = __builtin_amdgcn_readlane(lab[h >> 1], 32 * (h & 1) + jj);
+#pragma unroll
+                for (int s = 0; s < RL; s++) {
+                    // lj where the row has the edge, all ones where not: one min either way
+                    const uint32_t half = (uint32_t)(in[s][h >> 1] >> (32 * (h & 1)));
+                    const uint32_t e = (uint32_t)__builtin_amdgcn_sbfe((int)half, (uint32_t)jj, 1u);
+                    lab[s] = min(lab[s], lj | ~e);
+                }
+            }
+        }
+        changed = false;
+#pragma unroll
+        for (int s = 0; s < RL; s++) changed |= lab[s] != before[s];
+    } while (iterate && __any(changed));
+    FusedCounts out;
+    out.bad = bad;
+    out.kept = 0;
+#pragma unroll
+    for (int s = 0; s < RL; s++) {
+        const int row = lane + 64 * s;
+        if (W > 1 && !HAS_N && row < n) out.bad += n_code[s];
+        if (row < n) {
+            const bool kp = lab[s] == (uint32_t)row;
+            if (label) label[start + row] = start + lab[s];
+            kept[start + row] = kp ? 1 : 0;
+            if (root) root[start + row] = start + lab[s];
+            out.kept += kp ? 1u : 0u;
+        }
+    }
+    return out;
+}
+
 // Walks the bucket table itself (no task list to build or upload): wave w takes buckets
 // w, w + n_waves, ...; buckets with fewer than 2 or more than fused_max entries belong
 // to other kernels and are skipped.
 // KB >= 0: bit-sliced body with K = KB (k <= 3); KB < 0: the column-walking body (any k).
-template <bool HAS_N, int MODE, int KB>
+// W > 1: keys of W words (directional, KB >= 0 only: the host sends nothing else here).
+template <bool HAS_N, int MODE, int KB, int W = 1>
 __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__restrict__ keys,
                                                            const uint64_t *__restrict__ nmask,
                                                            const int32_t *__restrict__ freq,
@@ -658,7 +984,7 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
         if (n == 0 || n > fused_max) continue;
         if (n == 1) { // a position with one UMI: it survives
             if (lane == 0) {
-                label[start] = start;
+                if (label) label[start] = start;
                 kept[start] = 1;
                 if (root) root[start] = start;
                 bad += freq[start] < 1 ? 1u : 0u;
@@ -667,7 +993,15 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
             continue;
         }
         FusedCounts c;
-        if (KB >= 0) {
+        if ((KB >= 0 && MODE == MODE_DIRECTIONAL) || W > 1) {
+            constexpr int K = KB >= 0 ? KB : 0;
+            if (n <= 64)
+                c = small_bucket_body_dir<1, HAS_N, K, W>(keys, nmask, freq, percentage, start, (int)n, umi_len, label,
+                                                          kept, root);
+            else
+                c = small_bucket_body_dir<2, HAS_N, K, W>(keys, nmask, freq, percentage, start, (int)n, umi_len, label,
+                                                          kept, root);
+        } else if (KB >= 0) {
             constexpr int K = KB >= 0 ? KB : 0;
             if (n <= 64)
                 c = small_bucket_body_bs<1, HAS_N, MODE, K>(keys, nmask, freq, percentage, start, (int)n,
@@ -841,25 +1175,18 @@ hipError_t launch_prep(const uint64_t *keys, const uint64_t *nmask, const int32_
                        uint32_t n_ranges, uint32_t n, uint32_t fused_max, int umi_len, float percentage,
                        bool key32, void *fkey, int32_t *thr, uint32_t *label, uint32_t *lab,
                        unsigned long long *counters, const SegDesc *segs, int n_seg_parts,
-                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg, bool entries_too)
+                       uint32_t *bin_cnt, hipStream_t s, bool skip_seg, bool entries_too, uint32_t seg_from,
+                       int key_words, int full_umi_len)
 {
     if (n == 0 || (ranges && n_ranges == 0)) return hipSuccess;
-    if (entries_too)
-        prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
-                                                                         percentage, key32 ? 1 : 0, fkey, thr,
-                                                                         label, lab, counters, segs, n_seg_parts,
-                                                                         bin_cnt, skip_seg ? 1 : 0);
+    if (!entries_too) return hipSuccess; // every range is a segment's: its count kernel does it all
+    prep_kernel<<<ranges ? n_ranges : grid_for(n, 256), 256, 0, s>>>(keys, nmask, freq, ranges, n, umi_len,
+                                                                     percentage, key32 ? 1 : 0, fkey, thr,
+                                                                     label, lab, counters, segs, n_seg_parts,
+                                                                     bin_cnt, skip_seg ? 1 : 0, key_words, full_umi_len);
     bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets,
-                                                                     ranges ? fused_max : 0u, n, counters);
-    return hipGetLastError();
-}
-
-// the rises at bucket starts alone (the multi-word path has its own entry kernel)
-hipError_t launch_bucket_rise(const int32_t *freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
-                              unsigned long long *counters, hipStream_t s)
-{
-    if (n_buckets == 0) return hipSuccess;
-    bucket_rise_kernel<<<grid_for(n_buckets, 256, 512), 256, 0, s>>>(freq, bucket_off, n_buckets, 0u, n, counters);
+                                                                     ranges ? fused_max : 0u,
+                                                                     skip_seg ? seg_from : 0xFFFFFFFFu, n, counters);
     return hipGetLastError();
 }
 
@@ -903,16 +1230,53 @@ void launch_small_k(int kb, uint32_t blocks, const uint64_t *keys, const uint64_
 }
 } // namespace
 
+// The same for keys of n_words = 2..4 words (umi_len 22..85), directional, k <= 3.
+hipError_t launch_small_buckets_wide(const uint64_t *keys, const uint64_t *nmask, int n_words, const int32_t *freq,
+                                     float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
+                                     uint32_t fused_max, uint32_t n_entries, uint8_t *kept, uint32_t *root, int k,
+                                     int umi_len, unsigned long long *counters, uint32_t max_blocks, hipStream_t s)
+{
+    if (n_buckets == 0 || fused_max < 1) return hipSuccess;
+    if (k < 0 || k > 3 || n_words < 2 || n_words > 4) return hipErrorInvalidValue;
+    const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, max_blocks);
+#define UMI_LAUNCH_WIDE(HN, KB, WN)                                                                                \
+    small_bucket_kernel<HN, MODE_DIRECTIONAL, KB, WN><<<blocks, 256, 0, s>>>(keys, nmask, freq, percentage, bucket_off, \
+                                                                             n_buckets, fused_max, n_entries, nullptr,  \
+                                                                             kept, root, k, umi_len, 0, counters)
+#define UMI_LAUNCH_WIDE_K(HN, WN)                   \
+    switch (k) {                                    \
+    case 0: UMI_LAUNCH_WIDE(HN, 0, WN); break;      \
+    case 1: UMI_LAUNCH_WIDE(HN, 1, WN); break;      \
+    case 2: UMI_LAUNCH_WIDE(HN, 2, WN); break;      \
+    default: UMI_LAUNCH_WIDE(HN, 3, WN); break;     \
+    }
+#define UMI_LAUNCH_WIDE_W(HN)                       \
+    switch (n_words) {                              \
+    case 2: UMI_LAUNCH_WIDE_K(HN, 2); break;        \
+    case 3: UMI_LAUNCH_WIDE_K(HN, 3); break;        \
+    default: UMI_LAUNCH_WIDE_K(HN, 4); break;       \
+    }
+    if (nmask) { UMI_LAUNCH_WIDE_W(true) } else { UMI_LAUNCH_WIDE_W(false) }
+#undef UMI_LAUNCH_WIDE_W
+#undef UMI_LAUNCH_WIDE_K
+#undef UMI_LAUNCH_WIDE
+    return hipGetLastError();
+}
+
 // Every bucket of at most fused_max entries, start to finish: contract check, thresholds,
 // label, kept mask, root, survivor count.
 hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
                                 float percentage, const uint64_t *bucket_off, uint32_t n_buckets,
                                 uint32_t fused_max, uint32_t n_entries, uint32_t *label, uint8_t *kept, uint32_t *root,
                                 int k, int umi_len, bool sliced, int mode, int32_t adj_max_freq,
-                                unsigned long long *counters, hipStream_t s)
+                                unsigned long long *counters, uint32_t max_blocks, hipStream_t s)
 {
     if (n_buckets == 0 || fused_max < 1) return hipSuccess;
-    const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, 256 * 8);
+    // The waves are persistent over the bucket table: the grid should be what is resident at once.  Of
+    // a grid of 8 blocks per CU (the 32 waves a CU nominally holds) a quarter only starts when the
+    // first blocks have left and then works alone on its share of the table (SQ counters: the waves
+    // of that grid lived 57 % of the kernel's time) -- max_blocks comes from the context, 6 per CU.
+    const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, max_blocks);
     const int kb = (sliced && k >= 0 && k <= 3) ? k : -1;
     if (mode == MODE_DIRECTIONAL) {
         if (nmask) launch_small_k<true, MODE_DIRECTIONAL>(kb, blocks, keys, nmask, freq, percentage, bucket_off, n_buckets, fused_max, n_entries, label, kept, root, k, umi_len, adj_max_freq, counters, s);

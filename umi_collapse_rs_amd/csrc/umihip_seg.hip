@@ -24,76 +24,25 @@ constexpr int SCAN_PER_THREAD = SEG_SCAN_CHUNK / SCAN_THREADS; // 16 bins per th
 
 __device__ __forceinline__ uint32_t tasks_of_bin(uint32_t c) { return seg_tasks_of_bin(c); }
 
-// (entries, tasks) per scan chunk
-__global__ __launch_bounds__(SCAN_THREADS) void seg_scan_reduce_kernel(SegArgs g)
-{
-    __shared__ uint32_t part_e[SCAN_THREADS / 64], part_t[SCAN_THREADS / 64];
-    const SegScanChunk ch = g.chunks[blockIdx.x];
-    uint32_t e = 0, t = 0;
-    for (uint32_t b = threadIdx.x; b < ch.nbins; b += SCAN_THREADS) {
-        const uint32_t c = g.bin_cnt[ch.bin0 + b];
-        e += c;
-        t += tasks_of_bin(c);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        e += __shfl_down(e, off);
-        t += __shfl_down(t, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        part_e[threadIdx.x >> 6] = e;
-        part_t[threadIdx.x >> 6] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t se = 0, st = 0;
-        for (int w = 0; w < SCAN_THREADS / 64; w++) {
-            se += part_e[w];
-            st += part_t[w];
-        }
-        g.chunk_sums[blockIdx.x] = make_uint2(se, st);
-    }
-}
-
-// exclusive scan of the chunk sums, in place (one block); totals to the counters
-__global__ __launch_bounds__(1024) void seg_scan_spine_kernel(SegArgs g, unsigned long long *counters)
-{
-    __shared__ uint2 wsum[16];
-    __shared__ uint2 carry;
-    if (threadIdx.x == 0) carry = make_uint2(0u, 0u);
-    __syncthreads();
-    for (uint32_t base = 0; base < g.n_chunks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint2 v = i < g.n_chunks ? g.chunk_sums[i] : make_uint2(0u, 0u);
-        uint2 incl = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t ux = __shfl_up(incl.x, d), uy = __shfl_up(incl.y, d);
-            if ((int)(threadIdx.x & 63) >= d) {
-                incl.x += ux;
-                incl.y += uy;
-            }
-        }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint2 off = carry;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) {
-            off.x += wsum[w].x;
-            off.y += wsum[w].y;
-        }
-        if (i < g.n_chunks) g.chunk_sums[i] = make_uint2(off.x + incl.x - v.x, off.y + incl.y - v.y);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = make_uint2(off.x + incl.x, off.y + incl.y);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) counters[CNT_SEG_TASKS] = carry.y;
-}
-
-// bin_start, the task list, the pair count; bin_cnt is cleared for its second use as the
-// scatter cursor
-__global__ __launch_bounds__(SCAN_THREADS) void seg_scan_apply_kernel(SegArgs g, unsigned long long *counters)
+// Exclusive scan of the bin counts -> bin_start, the task list, the pair count: ONE launch, the
+// chunks chained by a decoupled look-back.  A block draws its chunk from a ticket counter (so that
+// every chunk before it has a block that is already running), sums its 256 bins' (entries, tasks),
+// publishes the sums, adds up what the chunks before it have published -- stopping at the first
+// that already knows its own prefix -- publishes its prefix and writes its bins.
+// Status word of a chunk: bit 63 = sums there, bit 31 = they include all chunks before; entries in
+// bits 32..62, tasks in bits 0..30 (both stay below 2^31: checked on the host); one 64-bit access.
+constexpr unsigned long long SCAN_HAVE = 1ull << 63, SCAN_PREFIX = 1ull << 31;
+__device__ __forceinline__ unsigned long long scan_pack(uint32_t e, uint32_t t) { return ((unsigned long long)e << 32) | t; }
+__global__ __launch_bounds__(SCAN_THREADS) void seg_scan_kernel(SegArgs g, unsigned long long *counters)
 {
     __shared__ uint2 wsum[SCAN_THREADS / 64];
-    const SegScanChunk ch = g.chunks[blockIdx.x];
-    const uint2 base = g.chunk_sums[blockIdx.x];
+    __shared__ uint32_t my_chunk;
+    __shared__ uint2 prefix;
+    unsigned long long *ticket = g.scan_state, *status = g.scan_state + 1;
+    if (threadIdx.x == 0) my_chunk = (uint32_t)atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const uint32_t ci = my_chunk;
+    const SegScanChunk ch = g.chunks[ci];
     // a thread owns SCAN_PER_THREAD consecutive bins
     uint32_t c[SCAN_PER_THREAD];
     uint2 mine = make_uint2(0u, 0u);
@@ -115,11 +64,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void seg_scan_apply_kernel(SegArgs g,
     }
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
+    if (threadIdx.x < 64) { // the first wave: the block's sums out, the look-back
+        uint2 tot = make_uint2(0u, 0u);
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            tot.x += wsum[w].x;
+            tot.y += wsum[w].y;
+        }
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&status[ci], SCAN_HAVE | (ci == 0 ? SCAN_PREFIX : 0ull) | scan_pack(tot.x, tot.y),
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        uint2 before = make_uint2(0u, 0u);
+        int64_t j0 = (int64_t)ci - 1; // lane l looks at chunk j0 - l
+        while (j0 >= 0) {
+            const int64_t j = j0 - lane;
+            unsigned long long st = SCAN_HAVE | SCAN_PREFIX; // (before the first chunk: an empty prefix)
+            if (j >= 0)
+                do st = __hip_atomic_load(&status[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while (!(st & SCAN_HAVE)); // (chunk j's block drew its ticket before this one: it is running)
+            const unsigned long long stops = __ballot((st & SCAN_PREFIX) != 0);
+            const int first = __ffsll(stops) - 1; // nearest chunk whose sums include everything before it
+            const bool take = first < 0 || lane <= first;
+            uint32_t e = take && j >= 0 ? (uint32_t)(st >> 32) & 0x7FFFFFFFu : 0u;
+            uint32_t t = take && j >= 0 ? (uint32_t)st & 0x7FFFFFFFu : 0u;
+            for (int off = 32; off > 0; off >>= 1) {
+                e += __shfl_xor(e, off);
+                t += __shfl_xor(t, off);
+            }
+            before.x += e;
+            before.y += t;
+            if (first >= 0) break;
+            j0 -= 64;
+        }
+        if (lane == 0) {
+            if (ci != 0)
+                __hip_atomic_store(&status[ci], SCAN_HAVE | SCAN_PREFIX | scan_pack(before.x + tot.x, before.y + tot.y),
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            prefix = before;
+            if (ci + 1 == g.n_chunks) counters[CNT_SEG_TASKS] = before.y + tot.y;
+        }
+    }
+    __syncthreads();
+    const uint2 base = prefix;
     uint2 off = make_uint2(base.x + incl.x - mine.x, base.y + incl.y - mine.y);
     for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) {
         off.x += wsum[w].x;
         off.y += wsum[w].y;
     }
+    // bin_start, the bins' tasks; bin_cnt is cleared for its second use as the scatter cursor
     unsigned long long pairs = 0;
 #pragma unroll
     for (int q = 0; q < SCAN_PER_THREAD; q++) {
@@ -295,21 +287,24 @@ __global__ __launch_bounds__(SEG_BLOCK_THREADS) void seg_count_lds_kernel(SegArg
     if (g.prep_keys) {
         // the entry kernel's work for this block's entries (prep_kernel, umihip_kernels.hip): filter
         // key, threshold (directional.rs:38), label, and the contract check -- freq >= 1, no N code
-        // without nmask, rises of freq (legal at a bucket's first entry only: bucket_rise_kernel
-        // counts those, the host wants the two counts equal)
+        // without nmask, no rise of freq inside the bucket (a segment is one bucket: its first entry
+        // is the one place where freq may rise; the host wants CNT_RISES == CNT_START_RISES, and
+        // this kernel adds to neither for that entry)
         unsigned int bad = 0, rises = 0;
         for (uint32_t i = blk.start + threadIdx.x; i < blk.end; i += SEG_BLOCK_THREADS) {
-            const uint64_t key = g.prep_keys[i];
-            const uint64_t nm = g.prep_nmask ? g.prep_nmask[i] : 0ull;
+            const uint64_t key = g.prep_keys[(size_t)i * g.key_words];
+            const uint64_t nm = g.prep_nmask ? g.prep_nmask[(size_t)i * g.key_words] : 0ull;
             const int32_t f = g.prep_freq[i];
             g.prep_thr[i] = threshold_of(g.prep_percentage, f);
             g.prep_label[i] = i;
-            const uint64_t k3 = key & ~nm;
+            const uint64_t k3 = key & ~nm & (g.umi_len >= 21 ? 0x7FFFFFFFFFFFFFFFull : ((1ull << (3 * g.umi_len)) - 1ull));
             store_filter_key(fkey, i, k3, g.umi_len);
             bad += f < 1 ? 1u : 0u;
             const uint64_t b2 = k3 & 0x4924924924924924ull;
             bad += (b2 & ~((k3 << 1) | (k3 << 2))) != 0 ? 1u : 0u;
-            rises += (i > 0 && f > g.prep_freq[i - 1]) ? 1u : 0u;
+            if (g.key_words > 1 && !g.prep_nmask)
+                bad += wide_n_codes(g.prep_keys + (size_t)i * g.key_words, g.key_words, g.full_umi_len);
+            rises += (i > sd->start && f > g.prep_freq[i - 1]) ? 1u : 0u;
         }
         if (__any(bad != 0u)) { // (rare: no reduction tree for it)
             if (bad) atomicAdd(&g.prep_counters[CNT_ERROR], (unsigned long long)bad);
@@ -547,7 +542,9 @@ __device__ __forceinline__ void uf_union_multi(uint32_t *parent, uint32_t (&u)[I
     }
 }
 
-template <typename KeyT, bool HAS_N, bool CK>
+// W > 1: keys of W words -- the filter keys hold the first word's 21 bases, every filter hit is decided
+// by the distance over all words (src/utils/bitset.rs:77-91, word by word)
+template <typename KeyT, bool HAS_N, bool CK, int W = 1>
 __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, float percentage,
                                                       uint32_t part, uint32_t n_parts)
 {
@@ -615,7 +612,16 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                 const uint32_t gi = sw ? cb[s].idx : ra[s].idx, gj = sw ? ra[s].idx : cb[s].idx;
                 const int32_t fi = sw ? cb[s].freq : ra[s].freq, fj = sw ? ra[s].freq : cb[s].freq;
                 int dist;
-                if (HAS_N) { // bitset.rs:85-87 (one word) and utils/mod.rs:25
+                if (W > 1) { // bitset.rs:77-91, word by word, and utils/mod.rs:25
+                    int res = 0;
+#pragma unroll
+                    for (int w = 0; w < W; w++) {
+                        const uint64_t ka = a.keys[(size_t)gi * W + w], kb = a.keys[(size_t)gj * W + w];
+                        const uint64_t xn = HAS_N ? a.nmask[(size_t)gi * W + w] ^ a.nmask[(size_t)gj * W + w] : 0ull;
+                        res += __builtin_popcountll(xn | (ka ^ kb)) - __builtin_popcountll(xn) / 3;
+                    }
+                    dist = res / 2;
+                } else if (HAS_N) { // bitset.rs:85-87 (one word) and utils/mod.rs:25
                     const uint64_t ka = a.keys[gi], kb = a.keys[gj];
                     const uint64_t xn = a.nmask[gi] ^ a.nmask[gj];
                     dist = (__builtin_popcountll(xn | (ka ^ kb)) - __builtin_popcountll(xn) / 3) / 2;
@@ -820,9 +826,7 @@ hipError_t launch_seg_build(const SegArgs &g, void *fkey, const int32_t *freq, b
         if (key32) seg_count_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (uint32_t *)fkey);
         else seg_count_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (uint64_t *)fkey);
     }
-    seg_scan_reduce_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g);
-    seg_scan_spine_kernel<<<1, 1024, 0, s>>>(g, counters);
-    seg_scan_apply_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g, counters);
+    seg_scan_kernel<<<g.n_chunks, SCAN_THREADS, 0, s>>>(g, counters);
     if (g.blocks) {
         if (key32) seg_scatter_lds_kernel<uint32_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint32_t *)fkey, freq);
         else seg_scatter_lds_kernel<uint64_t><<<g.n_blocks, SEG_BLOCK_THREADS, lds, s>>>(g, (const uint64_t *)fkey, freq);
@@ -862,9 +866,22 @@ hipError_t launch_seg_pairs(const PairArgs &a, const SegArgs &g, bool key32, flo
     } else if (key32) {
         if (has_n) seg_pair_kernel<uint32_t, true, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
         else seg_pair_kernel<uint32_t, false, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
-    } else {
+    } else if (g.key_words <= 1) {
         if (has_n) seg_pair_kernel<uint64_t, true, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
         else seg_pair_kernel<uint64_t, false, false><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);
+    } else {
+#define UMI_SEG_WIDE(WN)                                                                                           \
+    do {                                                                                                           \
+        if (has_n) seg_pair_kernel<uint64_t, true, false, WN><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);  \
+        else seg_pair_kernel<uint64_t, false, false, WN><<<n_blocks, 64, 0, s>>>(a, g, percentage, part, n_parts);       \
+    } while (0)
+        switch (g.key_words) {
+        case 2: UMI_SEG_WIDE(2); break;
+        case 3: UMI_SEG_WIDE(3); break;
+        case 4: UMI_SEG_WIDE(4); break;
+        default: return hipErrorInvalidValue;
+        }
+#undef UMI_SEG_WIDE
     }
     return hipGetLastError();
 }

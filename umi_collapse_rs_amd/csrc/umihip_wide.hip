@@ -19,38 +19,6 @@ namespace umihip {
 
 namespace {
 
-// thresholds, labels, contract check of the entries of ranges (umihip_kernels.hip's prep_kernel
-// for keys of W words; no filter key)
-template <int W>
-__global__ __launch_bounds__(256) void wide_prep_kernel(const uint64_t *__restrict__ keys,
-                                                        const uint64_t *__restrict__ nmask,
-                                                        const int32_t *__restrict__ freq,
-                                                        const RangeTask *__restrict__ ranges, int umi_len,
-                                                        float percentage, int32_t *__restrict__ thr,
-                                                        uint32_t *__restrict__ label,
-                                                        unsigned long long *__restrict__ counters)
-{
-    unsigned int bad = 0, rises = 0;
-    const RangeTask r = ranges[blockIdx.x];
-    for (uint32_t i = r.start + threadIdx.x; i < r.end; i += blockDim.x) {
-        const int32_t f = freq[i];
-        thr[i] = threshold_of(percentage, f);
-        label[i] = i;
-        bad += f < 1 ? 1u : 0u;
-        rises += (i > 0 && f > freq[i - 1]) ? 1u : 0u;
-        if (!nmask) { // nmask == NULL promises that no key holds the N code (100)
-            for (int b = 0; b < umi_len; b++) {
-                const int bit = 3 * b, w = bit >> 6, sh = bit & 63;
-                uint64_t c = keys[(size_t)i * W + w] >> sh;
-                if (sh > 61 && w + 1 < W) c |= keys[(size_t)i * W + w + 1] << (64 - sh); // a straddling base
-                bad += (c & 7ull) == 4ull ? 1u : 0u;
-            }
-        }
-    }
-    block_count_add(bad, &counters[CNT_ERROR]);
-    block_count_add(rises, &counters[CNT_RISES]);
-}
-
 // bitset.rs:77-91, word by word, then utils/mod.rs:25
 template <int W>
 __device__ __forceinline__ int wide_dist(const uint64_t (&ka)[W], const uint64_t (&na)[W], const uint64_t (&kb)[W],
@@ -145,20 +113,6 @@ __global__ __launch_bounds__(64) void wide_pair_kernel(PairArgs a, int n_words_u
 }
 
 } // namespace
-
-hipError_t launch_wide_prep(const uint64_t *keys, const uint64_t *nmask, const int32_t *freq,
-                            const RangeTask *ranges, uint32_t n_ranges, int n_words, int umi_len, float percentage,
-                            int32_t *thr, uint32_t *label, unsigned long long *counters, hipStream_t s)
-{
-    if (n_ranges == 0) return hipSuccess;
-    switch (n_words) {
-    case 2: wide_prep_kernel<2><<<n_ranges, 256, 0, s>>>(keys, nmask, freq, ranges, umi_len, percentage, thr, label, counters); break;
-    case 3: wide_prep_kernel<3><<<n_ranges, 256, 0, s>>>(keys, nmask, freq, ranges, umi_len, percentage, thr, label, counters); break;
-    case 4: wide_prep_kernel<4><<<n_ranges, 256, 0, s>>>(keys, nmask, freq, ranges, umi_len, percentage, thr, label, counters); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
 
 hipError_t launch_wide_pairs(const PairArgs &a, uint32_t n_tasks, int n_words, hipStream_t s)
 {
