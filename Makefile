@@ -7,12 +7,12 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unuse
 
 LIB := $(PKG)/libumihip.so
 OBJDIR := build/obj
-OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_wide.o $(OBJDIR)/umihip_api.o
+OBJS := $(OBJDIR)/umihip_kernels.o $(OBJDIR)/umihip_seg.o $(OBJDIR)/umihip_collapse.o $(OBJDIR)/umihip_stage.o $(OBJDIR)/umihip_radix.o $(OBJDIR)/umihip_wide.o $(OBJDIR)/umihip_api.o
 # development build (make dev): the shipped sources plus the round-1 tile kernels, their key sort
 # and their options (-DUMIHIP_DEV), as libumihip_dev.so; the legacy cross-check tests load it
 DEVDIR := build/obj_dev
 DEVLIB := $(PKG)/libumihip_dev.so
-DEVOBJS := $(DEVDIR)/umihip_kernels.o $(DEVDIR)/umihip_seg.o $(DEVDIR)/umihip_collapse.o $(DEVDIR)/umihip_stage.o $(DEVDIR)/umihip_wide.o $(DEVDIR)/umihip_api.o $(DEVDIR)/umihip_legacy.o $(DEVDIR)/umihip_sort.o
+DEVOBJS := $(DEVDIR)/umihip_kernels.o $(DEVDIR)/umihip_seg.o $(DEVDIR)/umihip_collapse.o $(DEVDIR)/umihip_stage.o $(DEVDIR)/umihip_radix.o $(DEVDIR)/umihip_wide.o $(DEVDIR)/umihip_api.o $(DEVDIR)/umihip_legacy.o $(DEVDIR)/umihip_sort.o
 HDRS := $(CSRC)/umihip_internal.h $(CSRC)/umihip_device.h $(CSRC)/umihip_plan.hpp include/umihip.h
 CLI := $(PKG)/bin/umicollapse
 
@@ -28,7 +28,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ -x hip $<
 
 $(LIB): $(OBJS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS) -ldl
 
 $(DEVDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(DEVDIR)
@@ -39,7 +39,7 @@ $(DEVDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DUMIHIP_DEV -c -o $@ -x hip $<
 
 $(DEVLIB): $(DEVOBJS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVOBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVOBJS) -ldl
 
 dev: $(DEVLIB)
 

@@ -105,6 +105,12 @@ def make_workload(cfg, rank, reads=None):
         return dict(cfg=cfg, st=st, umi_len=20, k=2, reads=reads, one_position=False,
                     workload="BASELINE config 5, one GPU's share (an eighth of 50 M reads): %d reads, 20-bp UMIs, "
                              "%d alignment positions, k=2 (molecule model)" % (reads, reads // 100))
+    if cfg == "wide24":
+        reads = reads or 1_000_000
+        st = synth.config2m(seed=24 + 1000 * rank, n_reads=reads, umi_len=24)
+        return dict(cfg=cfg, st=st, umi_len=24, k=1, reads=reads, one_position=True,
+                    workload="one deep alignment position of dual 12 + 12 UMIs (24 bases: keys of two words), molecule "
+                             "model: %d reads of %d molecules, error 0.01 per base" % (reads, st["n_molecules"]))
     raise SystemExit("unknown config " + cfg)
 
 
@@ -134,7 +140,8 @@ def cpu_baseline(wl, n_sample, p, all_cores=True):
         what = "the first %d buckets (%d unique UMIs)" % (nb, m)
     w = pairs_of(boff)
     t0 = time.perf_counter()
-    kept, _, calls = orc.dedup_batch(keys, None, freq, boff, umi_len, k, p)
+    run = orc.dedup_batch_wide if keys.ndim == 2 else orc.dedup_batch
+    kept, _, calls = run(keys, None, freq, boff, umi_len, k, p)
     dt = time.perf_counter() - t0
     reads = int(freq.astype(np.int64).sum())
     out = {"value": w / dt, "unit": "UMI-pair comparisons/s", "cores": 1, "kind": "port",
@@ -150,7 +157,7 @@ def cpu_baseline(wl, n_sample, p, all_cores=True):
         if cores > 1:
             t0 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(lambda _: orc.dedup_batch(keys, None, freq, boff, umi_len, k, p), range(cores)))
+                list(ex.map(lambda _: run(keys, None, freq, boff, umi_len, k, p), range(cores)))
             dta = time.perf_counter() - t0
             out["all_cores"] = {"value": cores * w / dta, "cores": cores, "reads_per_s": cores * reads / dta,
                                 "how": "one copy of the sample per core, concurrently (%.1f s)" % dta}
@@ -214,7 +221,8 @@ class Resident:
         self.n = len(st["keys"])
         self.boff = st["bucket_off"]
         self.w_local = pairs_of(self.boff)
-        self.d_keys = torch.from_numpy(st["keys"].view(np.int64)).to(dev)
+        self.n_words = st["keys"].shape[1] if st["keys"].ndim == 2 else 1
+        self.d_keys = torch.from_numpy(np.ascontiguousarray(st["keys"]).view(np.int64)).to(dev)
         self.d_freq = torch.from_numpy(st["freq"]).to(dev)
         self.d_kept = torch.zeros(max(1, self.n), dtype=torch.uint8, device=dev)
         self.d_boff = torch.from_numpy(np.ascontiguousarray(self.boff).view(np.int64)).to(dev)  # an input too
@@ -251,9 +259,14 @@ class Resident:
             s.setdefault("n_candidates", 0)
             s.setdefault("kernel_id", 0)
             return s
-        s = c.dedup_batch_device(self.d_keys.data_ptr(), 0, self.d_freq.data_ptr(), self.boff, wl["umi_len"],
-                                 self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p, stream=self.stream,
-                                 d_bucket_off=self.d_boff.data_ptr())
+        if self.n_words > 1:
+            s = c.dedup_batch_wide_device(self.d_keys.data_ptr(), 0, self.n_words, self.d_freq.data_ptr(), self.boff,
+                                          wl["umi_len"], self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p,
+                                          stream=self.stream)
+        else:
+            s = c.dedup_batch_device(self.d_keys.data_ptr(), 0, self.d_freq.data_ptr(), self.boff, wl["umi_len"],
+                                     self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p, stream=self.stream,
+                                     d_bucket_off=self.d_boff.data_ptr())
         if self.coll:  # all-gatherv of the kept mask: packed to bits on the device, padded all_gather
             slot = self.step_no & 1
             self.step_no += 1
@@ -418,11 +431,12 @@ def main():
     ap.add_argument("--split", action="store_true",
                     help="N>1 only: strong scaling -- ONE giant position (config 2), its pair work split over "
                          "the ranks, edge lists all-gathered, collapse replicated")
-    ap.add_argument("--config", default=None, choices=["2", "2m", "3", "4", "5"],
+    ap.add_argument("--config", default=None, choices=["2", "2m", "3", "4", "5", "wide24"],
                     help="the top-level workload per GPU (default: 2 at N=1, 4 at N>1): 2 = one giant position of "
                          "uniform UMIs, 2m = one deep position from the molecule model, 3 = 10M reads in 100k "
                          "positions, 4 = one GPU's share of the 8-GPU config (12.5M reads in 125k positions), 5 = "
-                         "one GPU's share of 50M reads with 20-bp UMIs, k=2")
+                         "one GPU's share of 50M reads with 20-bp UMIs, k=2, wide24 = one deep position of 24-base "
+                         "(dual 12 + 12) UMIs")
     ap.add_argument("--no-profile", action="store_true",
                     help="no HIP events inside the library's calls (phases_ms and the roofline's kernel time are then "
                          "missing): what the event records cost the step")
@@ -466,7 +480,7 @@ def main():
     cfg = args.config or ("2" if (world == 1 or split) else "4")
     extras = not args.no_extras
     if args.also is None:
-        also = [] if (not extras or split) else ([c for c in ("3", "5", "2m") if c != cfg] if world == 1
+        also = [] if (not extras or split) else ([c for c in ("3", "5", "2m", "wide24") if c != cfg] if world == 1
                                                  else [c for c in ("5", "2") if c != cfg])
     else:
         also = [] if args.also == "none" else [c for c in args.also.split(",") if c]
@@ -514,7 +528,7 @@ def main():
     # the same pass through the host-buffer entry point (H2D of keys/freq + D2H of the mask
     # inside the call): the PCIe-inclusive rate, reported beside `value`, never as it
     host_ms = None
-    if rank == 0 and world == 1 and extras:
+    if rank == 0 and world == 1 and extras and res.n_words == 1:
         ctx.dedup_batch(st["keys"], None, st["freq"], res.boff, wl["umi_len"], k=wl["k"], percentage=args.p,
                         want_root=False)
         t1 = time.perf_counter()

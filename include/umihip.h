@@ -99,7 +99,7 @@ const char *umi_last_error(void);
  *   "profile"        0/1: record HIP events, fill the ms_* fields of umi_stats
  *   "edge_capacity"  initial capacity of the permitted-pair list, entries (it grows by itself)
  *   "fused_max"      0..128 (default 128): largest bucket the fused one-wave-per-bucket kernel takes
- *   "fused_blocks"   1..16 (default 6): 256-thread blocks per CU of that kernel's persistent grid
+ *   "fused_blocks"   1..64 (default 12): 256-thread blocks per CU of that kernel's persistent grid
  *   "fused_sliced"   0/1 (default 1): that kernel's bit-sliced body for k <= 3 (0: columns one by one)
  *   "small_max"      (default 1024) largest bucket taken as 64-row popcount chunks; above, 2048-row tiles
  *   "seg_index"      0/1 (default 1): buckets of at least "seg_min" entries (default 512) are cut into
@@ -183,6 +183,17 @@ int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits,
                     const uint8_t *umi_ascii, const int32_t *score, uint64_t n_reads, int umi_len,
                     int merge, uint64_t *keys, uint64_t *nmask, int32_t *freq, uint64_t *rep,
                     uint64_t *bucket_off, uint64_t *n_entries, uint64_t *n_buckets);
+/* The same for UMIs of up to UMI_MAX_WIDE_UMI_LEN bases: keys / nmask hold n_words =
+ * ceil(3 * umi_len / 64) words per entry, entry-major (the input of umi_dedup_batch_wide). */
+int umi_stage_reads_wide_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits,
+                                const uint8_t *d_umi_ascii, const int32_t *d_score, uint64_t n_reads, int umi_len,
+                                int n_words, int merge, uint64_t *d_keys, uint64_t *d_nmask, int32_t *d_freq,
+                                uint64_t *d_rep, uint64_t *d_bucket_off, uint64_t *n_entries, uint64_t *n_buckets,
+                                void *hip_stream);
+int umi_stage_reads_wide(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits, const uint8_t *umi_ascii,
+                         const int32_t *score, uint64_t n_reads, int umi_len, int n_words, int merge, uint64_t *keys,
+                         uint64_t *nmask, int32_t *freq, uint64_t *rep, uint64_t *bucket_off, uint64_t *n_entries,
+                         uint64_t *n_buckets);
 
 /* ---- batched path: replaces the whole bucket loop
  *      src/deduplicate_sam.rs:207-233 (apply::<UcSAMRead,Naive> per bucket,
@@ -232,6 +243,22 @@ int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uin
  * to reassemble the mask of a bucket-sharded job (n / 8 bytes per rank instead of n). */
 int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_t *d_bits,
                          void *hip_stream);
+
+/* ---- one process, several GPUs, resident shards: the batched call on every device of a multi-device
+ *      context at once -- device r works on its own arrays d_*[r] (its share of the positions: the
+ *      iterations of src/deduplicate_sam.rs:207-233 share nothing but additive counters, so there is no
+ *      exchange on the data path), bucket_off[r] / n_buckets[r] are its host tables -- and then the
+ *      all-gatherv that reassembles the kept mask on every device: each device's mask packed to bits
+ *      (umi_pack_mask_device's layout), padded to slice_bytes, all-gathered over RCCL / xGMI into
+ *      d_mask_bits_all[r] (device r's buffer of n_devices * slice_bytes bytes; slice q = device q's
+ *      entries in its own order).  d_nmask, d_root, d_mask_bits_all may be NULL (no N anywhere / no roots
+ *      wanted / no gather); slice_bytes >= ceil(n_r / 8) for every r.  librccl.so is opened at the
+ *      first call that asks for the gather; the device ids of the context must then be distinct. */
+int umi_dedup_batch_device_multi(umi_ctx *ctx, const uint64_t *const *d_keys, const uint64_t *const *d_nmask,
+                                 const int32_t *const *d_freq, const uint64_t *const *bucket_off,
+                                 const uint64_t *n_buckets, int umi_len, int k, float percentage, int algo,
+                                 int32_t adj_max_freq, uint8_t *const *d_kept, uint32_t *const *d_root,
+                                 uint8_t *const *d_mask_bits_all, uint64_t slice_bytes, umi_stats *stats);
 
 /* ---- multi-GPU split of ONE call's all-pairs work (a single giant bucket
  *      does not shard by buckets).  Each of n_parts ranks holds the same inputs on its own

@@ -168,7 +168,13 @@ def stage_like_reference(recs, merge="mapqual", umi_len=0, sep=95, keep_unmapped
         scores.append(r["mapq"] if merge == "mapqual" else orc.avg_qual(list(r["qual"])))
         rec_idx.append(i)
     ub = np.frombuffer(b"".join(umis), dtype=np.uint8) if umis else np.zeros(0, np.uint8)
-    st = orc.stage_reads(bucket_ids, ub, scores, max(umi_len, 1), merge=0 if merge == "any" else 1)
+    if umi_len > 21:  # keys of several words: the oracle's staging is one-word, the plain-Python model is not
+        from helpers import stage_model
+        w_umis, w_freq, w_rep, w_off = stage_model(bucket_ids, [u.decode() for u in umis], scores, 0 if merge == "any" else 1)
+        wk, wm = orc.encode_keys_wide(w_umis)
+        st = dict(keys=wk, nmask=wm, freq=w_freq, rep=w_rep, bucket_off=w_off)
+    else:
+        st = orc.stage_reads(bucket_ids, ub, scores, max(umi_len, 1), merge=0 if merge == "any" else 1)
     st["rep"] = np.array(rec_idx, dtype=np.int64)[st["rep"].astype(np.int64)] if len(rec_idx) else st["rep"]
     st["umi_len"] = umi_len
     st["counters"] = counters
@@ -212,8 +218,9 @@ def paired_writer(recs, survivors):
 
 def expected_output(recs, k=1, p=0.5, algo="dir", **kw):
     st, pre = stage_like_reference(recs, **kw)
-    kept, _, _ = orc.dedup_batch(st["keys"], st["nmask"], st["freq"], st["bucket_off"],
-                                 st["umi_len"], k, p, 0 if algo == "dir" else 1)
+    dedup = orc.dedup_batch_wide if st["keys"].ndim == 2 else orc.dedup_batch
+    kept, _, _ = dedup(st["keys"], st["nmask"], st["freq"], st["bucket_off"], st["umi_len"], k, p,
+                       0 if algo == "dir" else 1)
     out = list(pre) + [int(st["rep"][i]) for i in np.nonzero(kept)[0]]
     if kw.get("paired"):
         out = paired_writer(recs, out)

@@ -122,3 +122,30 @@ def legacy_mark():
     import pytest
     return pytest.mark.skipif(not is_dev_build(), reason="round-1 tile kernels: development build only "
                                                           "(UMIHIP_LIB=.../libumihip_dev.so)")
+
+
+def stage_model(pos, umis, score, merge):
+    """deduplicate_sam.rs:148-176 + the canonical order, straight from the definition (a dict per
+    position, plain Python: for a few 10^4 reads): positions by first appearance, a position's UMIs
+    by freq descending then first appearance; per UMI its freq and the read that stands for it
+    (merge 0: the first; 1: the highest score, the earlier on ties).  Returns (list of UMI strings,
+    freq, rep, bucket_off)."""
+    buckets = {}
+    for i, (p, u) in enumerate(zip(pos, umis)):
+        d = buckets.setdefault(int(p), {})
+        e = d.get(u)
+        sc = 0 if score is None else int(score[i])
+        if e is None:
+            d[u] = [1, i, sc]  # freq, rep, score of the rep
+        else:
+            e[0] += 1
+            if merge and not (e[2] >= sc):
+                e[1], e[2] = i, sc
+    out_umis, freq, rep, off = [], [], [], [0]
+    for p, d in buckets.items():  # (dicts keep insertion order: first appearance)
+        items = sorted(d.items(), key=lambda kv: -kv[1][0])  # stable
+        out_umis += [u for u, _ in items]
+        freq += [e[0] for _, e in items]
+        rep += [e[1] for _, e in items]
+        off.append(len(out_umis))
+    return out_umis, np.array(freq, np.int32), np.array(rep, np.uint64), np.array(off, np.uint64)

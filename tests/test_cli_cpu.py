@@ -42,10 +42,12 @@ def test_bgzf_bam_round_trip(tmp_path):
 
 def read_staging(path):
     raw = open(path, "rb").read()
-    n, nb, umi_len, _ = struct.unpack_from("<4Q", raw, 0)
+    n, nb, umi_len, w = struct.unpack_from("<4Q", raw, 0)
     o = 32
-    keys = np.frombuffer(raw, np.uint64, n, o); o += 8 * n
-    nmask = np.frombuffer(raw, np.uint64, n, o); o += 8 * n
+    keys = np.frombuffer(raw, np.uint64, n * w, o); o += 8 * n * w
+    nmask = np.frombuffer(raw, np.uint64, n * w, o); o += 8 * n * w
+    if w > 1:  # keys of several words (UMIs beyond 21 bases): one row per entry
+        keys, nmask = keys.reshape(n, w), nmask.reshape(n, w)
     freq = np.frombuffer(raw, np.int32, n, o); o += 4 * n
     rep = np.frombuffer(raw, np.uint32, n, o); o += 4 * n
     off = np.frombuffer(raw, np.uint64, nb + 1, o)
@@ -68,6 +70,26 @@ def test_staging_matches_reference_restatement(tmp_path, merge, threads):
         assert (got[f] == exp[f]).all(), f
     assert (got["rep"].astype(np.int64) == exp["rep"]).all()
     assert got["nmask"].any() and len(got["bucket_off"]) > 121  # N bases, extra keys from strand/ref
+
+
+@pytest.mark.parametrize("umi_len,threads", [(24, 1), (24, 5), (45, 3), (85, 2)])
+def test_staging_of_long_umis_matches_the_definition(tmp_path, umi_len, threads):
+    """UMIs beyond 21 bases (dual 12 + 12: 24) through the host staging: keys of two to four words
+    (src/utils/bitset.rs:17-27), N bases, strands and references, against a plain-Python model of
+    deduplicate_sam.rs:148-176."""
+    header, recs = bamio.synthetic_bam(4, 60, 30, umi_len=umi_len, err=0.02)
+    src, dump = str(tmp_path / "in.bam"), str(tmp_path / "stage.bin")
+    write_bam(src, header, recs)
+    r = run(["-i", src, "-o", str(tmp_path / "unused.bam"), "--merge", "avgqual", "--dump-staging", dump,
+             "--num-threads", str(threads)])
+    assert r.returncode == 0, r.stderr
+    got = read_staging(dump)
+    exp, _ = bamio.stage_like_reference(recs, merge="avgqual")
+    assert got["umi_len"] == exp["umi_len"] == umi_len and got["keys"].shape[1] == (3 * umi_len + 63) // 64
+    for f in ("keys", "nmask", "freq", "bucket_off"):
+        assert (got[f] == exp[f]).all(), f
+    assert (got["rep"].astype(np.int64) == exp["rep"].astype(np.int64)).all()
+    assert got["nmask"].any()
 
 
 @pytest.mark.parametrize("flags,kw", [

@@ -52,6 +52,30 @@ def test_cli_variants_with_clips_strands_refs_and_n(tmp_path, extra, kw):
     assert orecs == exp
 
 
+@pytest.mark.parametrize("umi_len,extra", [(24, []), (24, ["--stage", "host", "-k", "2"]), (45, ["--merge", "avgqual"]),
+                                           (24, ["--devices", "0,0"])])
+def test_umis_beyond_21_bases_end_to_end(tmp_path, umi_len, extra):
+    """Dual 12 + 12 UMIs (24 bases) and longer: keys of several words through the device staging (or the
+    host's), the fused kernel and the segment index, one or two workers; the decompressed output stream
+    against the restatement (plain-Python staging model + the oracle's multi-word path)."""
+    header, recs = bamio.synthetic_bam(9, 120, 50, umi_len=umi_len, err=0.02)
+    rng = __import__("numpy").random.default_rng(umi_len)
+    centre = rng.integers(0, 4, umi_len)
+    for i in range(3000):  # one deep position of a few hundred clustered UMIs next to the small ones
+        u = centre.copy()
+        flip = rng.random(umi_len) < 0.08
+        u[flip] = rng.integers(0, 4, int(flip.sum()))
+        recs.append(bamio.make_record("d%d_%s" % (i, "".join("ACGT"[c] for c in u)), 0, 0, 777_000,
+                                      int(rng.integers(0, 61)), [("M", 50)], 50, bytes([30] * 50)))
+    kw = dict(merge="avgqual") if "avgqual" in extra else dict(merge="mapqual")
+    if "-k" in extra:
+        kw["k"] = 2
+    oh, orecs, log = run_cli(tmp_path, header, recs, extra + ["--num-threads", "4"])
+    exp, st = bamio.expected_output(recs, **kw)
+    assert oh == header and orecs == exp
+    assert "Number of UMIs: %d" % len(st["keys"]) in log
+
+
 def test_deep_position_with_and_without_pruning(tmp_path):
     """One position with ~6,000 distinct 8-bp UMIs (bit-sliced tiles; label propagation over a
     giant component): --data naive (plain all-pairs) and the default --data (range pruning) must

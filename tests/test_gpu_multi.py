@@ -262,3 +262,57 @@ def test_bench_rehearsal_two_ranks_over_gloo_and_one_rank_over_rccl(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["collective"] == "nccl" and line["value"] > 0
+
+
+def _rccl_one_process_worker(q):
+    """(its own process: RCCL stays out of the test runner)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import umi_collapse_rs_amd as umi
+    keys, nm, fr, off = _mixed_batch(31337)
+    dev = torch.device("cuda", 0)
+    n = len(keys)
+    slice_bytes = (n + 7) // 8 + 5  # (padding: the slices of a real job differ in length)
+    t_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+    t_fr = torch.from_numpy(fr).to(dev)
+    t_kept = torch.zeros(n, dtype=torch.uint8, device=dev)
+    t_root = torch.zeros(n, dtype=torch.int32, device=dev)
+    t_bits = torch.full((slice_bytes,), 0xAA, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx = umi.Context([0])  # a multi-device context of one device: all RCCL can be given on this box
+    try:
+        st = ctx.dedup_batch_device_multi([dict(d_keys=t_keys.data_ptr(), d_freq=t_fr.data_ptr(), bucket_off=off,
+                                                d_kept=t_kept.data_ptr(), d_root=t_root.data_ptr(),
+                                                d_bits_all=t_bits.data_ptr())], 12, slice_bytes, k=1)
+        st2 = ctx.dedup_batch_device_multi([dict(d_keys=t_keys.data_ptr(), d_freq=t_fr.data_ptr(), bucket_off=off,
+                                                 d_kept=t_kept.data_ptr())], 12, slice_bytes, k=1, gather=False)
+    finally:
+        ctx.close()
+    torch.cuda.synchronize()
+    q.put((t_kept.cpu().numpy().tobytes(), t_root.cpu().numpy().tobytes(), t_bits.cpu().numpy().tobytes(),
+           st["n_kept"], st2["n_kept"], slice_bytes))
+
+
+def test_rccl_all_gather_behind_the_c_abi_with_one_device():
+    """umi_dedup_batch_device_multi: per-device resident shards through the ordinary pipeline, masks
+    packed to bits and all-gathered by RCCL inside the library (ncclCommInitAll + grouped
+    ncclAllGather, librccl opened on first use).  The communicator here has ONE rank -- the box has
+    one GPU and RCCL refuses a device named twice -- so what this shows is that the library's own
+    collective path runs end to end and leaves the right bytes; N > 1 is the driver's to observe."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_process_worker, args=(q,))
+    p.start()
+    kept_b, root_b, bits_b, n_kept, n_kept2, slice_bytes = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    keys, nm, fr, off = _mixed_batch(31337)
+    okept, oroot, _ = orc.dedup_batch(keys, None, fr, off, 12, 1)
+    kept = np.frombuffer(kept_b, np.uint8)
+    assert (kept == okept).all() and (np.frombuffer(root_b, np.uint32) == oroot).all()
+    assert n_kept == n_kept2 == int(okept.sum())
+    bits = np.frombuffer(bits_b, np.uint8)
+    want = np.packbits(okept, bitorder="little")
+    assert len(bits) == slice_bytes and (bits[:len(want)] == want).all() and (bits[len(want):] == 0).all()

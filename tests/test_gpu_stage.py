@@ -130,3 +130,38 @@ def test_device_form_runs_on_the_callers_stream_default_stream_included(ctx):
     assert (d_freq[:ne].cpu().numpy() == want["freq"]).all()
     assert (outs[2][:ne].cpu().numpy().view(np.uint64) == want["rep"]).all()
     assert (d_off[:nb + 1].cpu().numpy().view(np.uint64) == want["bucket_off"]).all()
+
+
+@pytest.mark.parametrize("L,n_reads,n_pos,n_mol,n_frac,merge,sorted_file", [
+    (24, 30000, 400, 10, 0.0, 1, True),     # dual 12 + 12 UMIs: two words
+    (22, 20000, 1, 4000, 0.01, 0, False),   # one deep position, the straddling base 21 (may be N)
+    (45, 20000, 3000, 3, 0.002, 1, False),  # three words, positions interleaved
+    (85, 5000, 50, 20, 0.0, 1, True),       # four words
+    (12, 20000, 300, 8, 0.01, 1, False),    # one word, against the same model
+])
+def test_staging_of_umis_of_any_length_against_the_definition(ctx, L, n_reads, n_pos, n_mol, n_frac, merge, sorted_file):
+    """umi_stage_reads_wide against a plain-Python model of deduplicate_sam.rs:148-176 (a dict per
+    position) with the canonical order: keys (all words), N masks, freq, representative reads, table."""
+    from helpers import stage_model
+    rng = np.random.default_rng(31 * L + merge)
+    pos, umi, score = make_reads(rng, n_reads, n_pos, L, n_mol, n_frac=n_frac, sorted_file=sorted_file)
+    strings = [bytes(umi[i * L:(i + 1) * L]).decode() for i in range(n_reads)]
+    w_umis, w_freq, w_rep, w_off = stage_model(pos, strings, score, merge)
+    words = (3 * L + 63) // 64
+    wk, wm = orc.encode_keys_wide(w_umis) if words > 1 else tuple(x.reshape(-1, 1) for x in orc.encode_keys(w_umis))
+    key = (pos.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    for akey, bits in ((key, 64), (dense_ids(pos).astype(np.uint64), max(1, int(dense_ids(pos).max()).bit_length()))):
+        got = ctx.stage_reads_wide(akey, umi, score, L, merge, align_key_bits=bits)
+        assert (got["bucket_off"] == w_off).all()
+        assert (got["keys"] == wk).all() and (got["nmask"] == wm).all()
+        assert (got["freq"] == w_freq).all() and (got["rep"] == w_rep).all()
+    # ... and what it feeds: the batched call on the staged arrays against the oracle on the model's
+    st = got
+    kept, root, _ = ctx.dedup_batch_wide(st["keys"], st["nmask"] if st["nmask"].any() else None, st["freq"],
+                                         st["bucket_off"], L, k=1) if words > 1 else ctx.dedup_batch(
+        st["keys"][:, 0], st["nmask"][:, 0] if st["nmask"].any() else None, st["freq"], st["bucket_off"], L, k=1)
+    if words > 1:
+        okept, oroot, _ = orc.dedup_batch_wide(wk, wm, w_freq, w_off, L, 1)
+    else:
+        okept, oroot, _ = orc.dedup_batch(wk[:, 0], wm[:, 0], w_freq, w_off, L, 1)
+    assert (kept == okept).all() and (root == oroot).all()

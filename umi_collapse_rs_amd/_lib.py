@@ -58,6 +58,11 @@ SIGNATURES = {
                                          C.c_void_p, _u64p, _u64p, C.c_void_p]),
     "umi_stage_reads": (C.c_int, [C.c_void_p, _u64p, C.c_int, _u8p, _i32p, C.c_uint64, C.c_int, C.c_int,
                                   _u64p, _u64p, _i32p, _u64p, _u64p, _u64p, _u64p]),
+    "umi_stage_reads_wide_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, _u64p, _u64p, C.c_void_p]),
+    "umi_stage_reads_wide": (C.c_int, [C.c_void_p, _u64p, C.c_int, _u8p, _i32p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                       _u64p, _u64p, _i32p, _u64p, _u64p, _u64p, _u64p]),
     "umi_dedup_batch": (C.c_int, [C.c_void_p, _u64p, _u64p, _i32p, _u64p, C.c_uint64, C.c_int,
                                   C.c_int, C.c_float, C.c_int, C.c_int32, _u8p, _u32p,
                                   C.POINTER(Stats)]),
@@ -70,6 +75,11 @@ SIGNATURES = {
                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(Stats)]),
     "umi_pack_mask_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "umi_dedup_batch_device_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int,
+                                               C.c_float, C.c_int, C.c_int32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint64,
+                                               C.POINTER(Stats)]),
     "umi_pairs_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u64p,
                                            C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
                                            C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,

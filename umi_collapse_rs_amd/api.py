@@ -148,6 +148,25 @@ class Context:
         e, b = int(ne.value), int(nb.value)
         return dict(keys=keys[:e], nmask=nm[:e], freq=freq[:e], rep=rep[:e], bucket_off=boff[:b + 1])
 
+    def stage_reads_wide(self, align_key, umi_bytes, score, umi_len, merge=1, align_key_bits=64):
+        """stage_reads for UMIs of any length up to 85 bases: keys / nmask come back as uint64
+        [n_entries, n_words] (the input of dedup_batch_wide; one column for umi_len <= 21)."""
+        align_key = np.ascontiguousarray(align_key, dtype=np.uint64)
+        umi_bytes = np.ascontiguousarray(umi_bytes, dtype=np.uint8)
+        sc = None if score is None else np.ascontiguousarray(score, dtype=np.int32)
+        n, w = len(align_key), (3 * umi_len + 63) // 64
+        assert len(umi_bytes) == n * umi_len
+        m = max(1, n)
+        keys, nm = np.zeros((m, w), np.uint64), np.zeros((m, w), np.uint64)
+        rep, freq, boff = np.zeros(m, np.uint64), np.zeros(m, np.int32), np.zeros(m + 1, np.uint64)
+        ne, nb = C.c_uint64(0), C.c_uint64(0)
+        check(load().umi_stage_reads_wide(self._h, ptr(align_key, C.c_uint64), align_key_bits, ptr(umi_bytes, C.c_uint8),
+                                          ptr(sc, C.c_int32), n, umi_len, w, merge, ptr(keys, C.c_uint64),
+                                          ptr(nm, C.c_uint64), ptr(freq, C.c_int32), ptr(rep, C.c_uint64),
+                                          ptr(boff, C.c_uint64), C.byref(ne), C.byref(nb)))
+        e, b = int(ne.value), int(nb.value)
+        return dict(keys=keys[:e], nmask=nm[:e], freq=freq[:e], rep=rep[:e], bucket_off=boff[:b + 1])
+
     def stage_reads_device(self, d_align_key, d_umi, d_score, n_reads, umi_len, d_keys, d_nmask, d_freq,
                            d_rep, d_bucket_off, merge=1, align_key_bits=64, stream=0):
         """The same with everything in device memory (raw pointers); returns (n_entries, n_buckets)."""
@@ -171,6 +190,39 @@ class Context:
                                                   C.byref(st)))
         return st.as_dict()
 
+
+    def dedup_batch_device_multi(self, shards, umi_len, slice_bytes, k=1, percentage=0.5, algo=UMI_ALGO_DIRECTIONAL,
+                                 adj_max_freq=0, gather=True):
+        """umi_dedup_batch_device_multi on a multi-device context: shards = one dict per device with the
+        device addresses d_keys, d_freq, d_kept (and optionally d_nmask, d_root), the host array
+        bucket_off, and d_bits_all (n_devices * slice_bytes bytes on that device) for the RCCL
+        all-gather of the packed kept masks.  Returns the merged stats."""
+        nd = len(shards)
+        boffs = [np.ascontiguousarray(sh["bucket_off"], dtype=np.uint64) for sh in shards]
+
+        def ptrs(name, required=True):
+            vals = [sh.get(name) or None for sh in shards]
+            if not required and all(v is None for v in vals):
+                return None
+            return (C.c_void_p * nd)(*vals)
+        st = Stats()
+        off_arr = (_lib._u64p * nd)(*[ptr(b, C.c_uint64) for b in boffs])
+        nb_arr = (C.c_uint64 * nd)(*[len(b) - 1 for b in boffs])
+        check(load().umi_dedup_batch_device_multi(self._h, ptrs("d_keys"), ptrs("d_nmask", False), ptrs("d_freq"), off_arr,
+                                                  nb_arr, umi_len, k, percentage, algo, adj_max_freq, ptrs("d_kept"),
+                                                  ptrs("d_root", False), ptrs("d_bits_all") if gather else None,
+                                                  slice_bytes, C.byref(st)))
+        return st.as_dict()
+
+    def dedup_batch_wide_device(self, d_keys, d_nmask, n_words, d_freq, bucket_off, umi_len, d_kept, d_root=0, k=1,
+                                percentage=0.5, algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0, stream=0):
+        """Device-pointer batched call for keys of n_words words per entry (umi_len > 21)."""
+        bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+        st = Stats()
+        check(load().umi_dedup_batch_wide_device(self._h, d_keys, d_nmask or None, n_words, d_freq, ptr(bucket_off, C.c_uint64),
+                                                 len(bucket_off) - 1, umi_len, k, percentage, algo, adj_max_freq, d_kept,
+                                                 d_root or None, stream or None, C.byref(st)))
+        return st.as_dict()
 
     def pack_mask_device(self, d_kept, n, d_bits, stream=0):
         """kept bytes -> bits on the device (umi_pack_mask_device), enqueued on `stream`."""

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -16,6 +17,8 @@
 
 #include "umihip_internal.h"
 #include "umihip_plan.hpp"
+
+#include <rccl/rccl.h> // (types only: the library itself is opened when the first collective is asked for)
 
 using namespace umihip;
 
@@ -75,6 +78,8 @@ struct DevBuf {
 };
 
 constexpr int MAX_ROUNDS = 1 << 20;
+constexpr int DAG_ROUNDS = 3; // one-way rounds enqueued before the host first looks (freq at least
+                              // halves along a one-way pair at p <= 0.5: depth 2 at config 2)
 
 // grow-only pinned host buffer; every write goes through put(), which checks the extent
 struct PinnedBuf {
@@ -112,7 +117,52 @@ struct PinnedBuf {
 
 } // namespace
 
+// RCCL, opened on first use (dlopen: a process that never asks for a collective -- the umicollapse
+// program, a single-GPU host -- does not map it; one that already holds a copy, PyTorch's, gets that
+// copy instead of a second one beside it)
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    bool load()
+    {
+        if (handle) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) {
+            error = std::string("cannot open librccl.so: ") + dlerror();
+            return false;
+        }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(handle, name);
+            if (!p && error.empty()) error = std::string("librccl.so lacks ") + name;
+            return p;
+        };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!error.empty()) {
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+
 struct umi_ctx {
+    // the communicators of a multi-device context's devices (umi_dedup_batch_device_multi), made on first use
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;
     // a multi-device context (umi_ctx_create_multi) owns one ordinary context per device and has
     // no device state of its own; an ordinary one has no subs
     std::vector<umi_ctx *> subs;
@@ -138,7 +188,7 @@ struct umi_ctx {
     uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 128 per CU; items are dealt
                                // statically over them, the dispatcher evens out the rest)
     uint32_t fused_max = FUSED_MAX;
-    uint32_t fused_blocks = 6; // 256-thread blocks per CU of the fused kernel's persistent grid
+    uint32_t fused_blocks = 12; // 256-thread blocks per CU of the fused kernel's persistent grid
     bool fused_sliced = true;
     int bs_unit = 2;
     bool bs_sorted = LEGACY_DEFAULT; // sort large buckets by key and reuse prefix state along column runs
@@ -162,8 +212,6 @@ struct umi_ctx {
     DevBuf fkey, thr, label, lab, edges, edge_dist, ovf, counters, boff, status, blocked;
     DevBuf plan_tables; // ranges, segment descriptors, scan chunks, popcount tile tasks: one upload
     DevBuf bs_tasks, plane_tasks, planes, tab_rows, tab_items;
-    DevBuf collapse_flags; // barrier flag words of the fused collapse kernel's blocks
-    uint32_t collapse_epoch = 0;
     DevBuf seg_bin_cnt, seg_bin_start, seg_tasks, seg_sub_rec, seg_priv_edges, seg_priv_dist, seg_priv_cnt;
     PinnedBuf h_plan_alt[2]; // staging of the plan's tables, in turn; [plan_flip ^ 1] = what plan_tables holds
     int plan_flip = 0;
@@ -184,8 +232,6 @@ struct umi_ctx {
     unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES)
     uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
     uint32_t *d_changed() const { return (uint32_t *)(counters.as<unsigned long long>() + CNT_COUNT); }
-    uint32_t *h_sync() const { return (uint32_t *)((char *)h_counters + CTRL_SYNC_OFF); }
-    uint32_t *d_sync() const { return (uint32_t *)((char *)counters.p + CTRL_SYNC_OFF); }
     static constexpr int N_EVENTS = 10;
     hipEvent_t ev[N_EVENTS] = {};
 };
@@ -353,7 +399,6 @@ class Pipeline {
     uint64_t n_edges = 0;  // entries the pair kernels appended to the edge list
     uint64_t n_direct = 0; // symmetric pairs united where they were found
     uint64_t seg_tasks_made = 0;
-    uint32_t seg_grid = 0; // blocks of the segment index's pair kernel = its private edge slots
     uint32_t cap_used = 0;
     const void *bs_fkey = nullptr;   // filter keys the bit-sliced tiles are cut from
     [[maybe_unused]] const uint32_t *bs_perm = nullptr;
@@ -899,9 +944,7 @@ class Pipeline {
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[8], s));
             seg_timed = true;
-            seg_grid = blocks;
-            // (the batched directional path reads the blocks' private slots where they are)
-            if (!(one_sync() && seg.uf_parent)) HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
+            HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
             st.n_pair_launches += 1;
         }
 #ifdef UMIHIP_DEV
@@ -1018,13 +1061,11 @@ class Pipeline {
     }
 
     // The batched directional path with one synchronisation: pair kernels, union-find over the
-    // symmetric pairs, then ONE launch for the rest -- forest flattened, rounds along the one-way
-    // pairs until one is quiet, kept mask -- all enqueued behind one another (the kernels read the
-    // edge count on the device), the control block read once.  What the host may find then: the
-    // edge list ran over (longer list, pairs and collapse again); the fused collapse gave up at a
-    // barrier (its grid was not resident at once: the phases again as separate launches); or its
-    // last round still moved a label (more rounds, finalize again).
-    bool slots_direct() const { return pl.seg_parts && seg.uf_parent != nullptr; }
+    // symmetric pairs, forest flattened, DAG_ROUNDS rounds along the one-way pairs, kept mask -- all
+    // enqueued behind one another (the kernels read the edge count on the device; a round is a no-op
+    // once the one before it was quiet), the control block read once.  What the host may find then:
+    // the edge list ran over (longer list, pairs and collapse again), or the last round still moved a
+    // label (more rounds, finalize again).
     CollapseDesc collapse_desc() const
     {
         CollapseDesc d;
@@ -1032,9 +1073,6 @@ class Pipeline {
         d.lab = ctx->lab.as<uint32_t>();
         d.edges = ctx->edges.as<uint2>();
         d.edge_cap = cap_used;
-        d.priv_edges = slots_direct() ? seg.priv_edges : nullptr;
-        d.priv_cnt = seg.priv_cnt;
-        d.n_slots = seg_grid;
         d.ranges = d_ranges;
         d.n_ranges = (uint32_t)pl.ranges.size();
         d.n = n;
@@ -1042,9 +1080,6 @@ class Pipeline {
         d.root = d_root;
         d.counters = d_cnt;
         d.changed = ctx->d_changed();
-        d.sync = ctx->d_sync();
-        d.flags = ctx->collapse_flags.as<uint32_t>();
-        d.epoch = ctx->collapse_epoch;
         return d;
     }
     int run_one_sync()
@@ -1066,8 +1101,10 @@ class Pipeline {
                 // when it does not unite them itself
                 if (!seg.uf_parent || legacy_tiles() || !pl.small_tasks.empty() || !pl.big_tasks.empty())
                     HIP_TRY(launch_uf_union_list(ctx->edges.as<uint2>(), d_cnt, cap_used, d_label, cap_used, s));
-                ctx->collapse_epoch += COLLAPSE_EPOCH_STEP; // (MAX_ROUNDS_PER_SYNC + 2 barriers at most per launch)
-                HIP_TRY(launch_collapse_fused(collapse_desc(), (uint32_t)ctx->n_cus, s));
+                const CollapseDesc cd = collapse_desc();
+                HIP_TRY(launch_collapse_flatten(cd, s));
+                for (int r = 0; r < DAG_ROUNDS; r++) HIP_TRY(launch_collapse_round(cd, r, s));
+                HIP_TRY(launch_collapse_finalize(cd, s));
             } else { // no pair of this call reaches the edge list: every entry outside the fused buckets survives
                 HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
             }
@@ -1090,28 +1127,17 @@ class Pipeline {
             HIP_TRY(hipMemsetAsync(d_changed, 0, CTRL_BYTES - CTRL_FLAGS_OFF, s)); // flags and sync words
             HIP_TRY(launch_iota(d_label, n, s)); // (the fused buckets' entries are finished: their labels are free)
         }
-        const uint32_t *h_sync = ctx->h_sync();
-        st.n_edges = n_edges + n_direct + (have_pairs ? h_sync[3] : 0u);
-        int rounds = 0;
-        if (have_pairs) {
-            const bool gave_up = h_sync[1] != 0;
-            rounds = (st.n_edges ? 1 : 0) + (gave_up ? 0 : (int)h_sync[2]);
-            if (gave_up || ctx->h_changed()[MAX_ROUNDS_PER_SYNC - 1]) {
-                // flatten is idempotent and lab[] only ever falls: the phases run again, or go on, as
-                // separate launches over the state the fused kernel left
-                const CollapseDesc cd = collapse_desc();
-                if (gave_up) {
-                    // (the barrier it stopped at may have left arrivals in its counters)
-                    HIP_TRY(hipMemsetAsync(ctx->collapse_flags.p, 0, COLLAPSE_BARRIER_WORDS * sizeof(uint32_t), s));
-                    HIP_TRY(launch_collapse_flatten(cd, s)); // (lab[] starts over as the identity)
-                }
-                if ((rc = run_rounds(ctx, s, [&](uint32_t *, int r) { return launch_collapse_round(cd, r, s); },
-                                     rounds, 4)))
-                    return rc;
-                HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
-                HIP_TRY(launch_collapse_finalize(cd, s));
-                if ((rc = read_control())) return rc;
-            }
+        st.n_edges = n_edges + n_direct;
+        int rounds = have_pairs && st.n_edges ? 1 : 0;
+        for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
+        if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
+            // (comp[] is flat and lab[] only ever falls: the rounds go on where the first ones stopped)
+            const CollapseDesc cd = collapse_desc();
+            if ((rc = run_rounds(ctx, s, [&](uint32_t *, int r) { return launch_collapse_round(cd, r, s); }, rounds, 4)))
+                return rc;
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
+            HIP_TRY(launch_collapse_finalize(cd, s));
+            if ((rc = read_control())) return rc;
         }
         st.n_rounds = (uint32_t)rounds;
         return finish_stats();
@@ -1631,8 +1657,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     if (err == hipSuccess)
         err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES);
     for (int i = 0; i < umi_ctx::N_EVENTS && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
-    if (err == hipSuccess && ctx->collapse_flags.reserve(COLLAPSE_BARRIER_WORDS * sizeof(uint32_t)) != UMI_OK) err = hipErrorOutOfMemory;
-    if (err == hipSuccess) err = hipMemset(ctx->collapse_flags.p, 0, COLLAPSE_BARRIER_WORDS * sizeof(uint32_t));
+
     if (err != hipSuccess) {
         umi_ctx_destroy(ctx);
         return fail(UMI_ERR_HIP, "context setup failed: %s", hipGetErrorString(err));
@@ -1645,6 +1670,8 @@ void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
     if (!ctx->subs.empty()) { // a multi-device context: nothing of its own on a device
+        for (ncclComm_t c : ctx->comms)
+            if (c && ctx->rccl.CommDestroy) (void)ctx->rccl.CommDestroy(c);
         for (umi_ctx *sub : ctx->subs) umi_ctx_destroy(sub);
         delete ctx;
         return;
@@ -1653,7 +1680,7 @@ void umi_ctx_destroy(umi_ctx *ctx)
     ctx->sh_in.release();
     ctx->sh_out.release();
     DevBuf *bufs[] = {&ctx->tab_rows, &ctx->tab_items, &ctx->bs_tasks, &ctx->plane_tasks, &ctx->planes, &ctx->plan_tables, &ctx->fkey_sorted, &ctx->perm,
-                      &ctx->collapse_flags, &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_tasks,
+                      &ctx->seg_bin_cnt, &ctx->seg_bin_start, &ctx->seg_tasks,
                       &ctx->seg_sub_rec, &ctx->seg_priv_edges, &ctx->seg_priv_dist, &ctx->seg_priv_cnt,
                       &ctx->iota, &ctx->sort_tmp, &ctx->sample_pos, &ctx->sample_out,
                       &ctx->fkey,    &ctx->thr,      &ctx->label,    &ctx->lab,      &ctx->edges,    &ctx->ovf,
@@ -1746,7 +1773,7 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
     } else if (!strcmp(name, "fused_sliced")) {
         ctx->fused_sliced = value != 0;
     } else if (!strcmp(name, "fused_blocks")) {
-        if (value < 1 || value > 16) return fail(UMI_ERR_ARG, "fused_blocks must be in 1..16");
+        if (value < 1 || value > 64) return fail(UMI_ERR_ARG, "fused_blocks must be in 1..64");
         ctx->fused_blocks = (uint32_t)value;
     } else if (!strcmp(name, "fused_max")) {
         if (value < 0) return fail(UMI_ERR_ARG, "fused_max must be >= 0");
@@ -1940,47 +1967,60 @@ int umi_dedup_batch_wide(umi_ctx *ctx, const uint64_t *keys, const uint64_t *nma
                               percentage, algo, adj_max_freq, kept, root, stats, n_words);
 }
 
-int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits, const uint8_t *d_umi_ascii,
-                           const int32_t *d_score, uint64_t n_reads, int umi_len, int merge, uint64_t *d_keys,
-                           uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
-                           uint64_t *n_entries, uint64_t *n_buckets, void *hip_stream)
+int umi_stage_reads_wide_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits, const uint8_t *d_umi_ascii,
+                                const int32_t *d_score, uint64_t n_reads, int umi_len, int n_words, int merge,
+                                uint64_t *d_keys, uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep,
+                                uint64_t *d_bucket_off, uint64_t *n_entries, uint64_t *n_buckets, void *hip_stream)
 {
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
     if (!ctx->subs.empty()) ctx = ctx->subs[0]; // (staging runs on the first device of a multi-device context)
     if (!n_entries || !n_buckets || !d_bucket_off) return fail(UMI_ERR_ARG, "n_entries / n_buckets / d_bucket_off is NULL");
     if (n_reads && (!d_align_key || !d_umi_ascii || !d_keys || !d_freq || !d_rep))
         return fail(UMI_ERR_ARG, "a required device pointer is NULL");
-    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (umi_len < 1 || umi_len > UMI_MAX_WIDE_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_WIDE_UMI_LEN);
+    if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
     if (align_key_bits < 1 || align_key_bits > 64) return fail(UMI_ERR_ARG, "align_key_bits must be in 1..64");
     if (merge != 0 && merge != 1) return fail(UMI_ERR_ARG, "merge must be 0 (any) or 1 (highest score, first on ties)");
     if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads)))) return rc;
+    if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads, n_words)))) return rc;
     hipStream_t s = (hipStream_t)hip_stream; // (NULL = the default stream, as in every device-pointer call)
     const int r = stage_reads_on_device(ctx->stage_ws.p, d_align_key, align_key_bits, d_umi_ascii, d_score,
-                                        (uint32_t)n_reads, umi_len, merge, d_keys, d_nmask, d_freq, d_rep, d_bucket_off,
-                                        n_entries, n_buckets, ctx->h_counters, s);
+                                        (uint32_t)n_reads, umi_len, n_words, merge, d_keys, d_nmask, d_freq, d_rep,
+                                        d_bucket_off, n_entries, n_buckets, ctx->h_counters, s);
     if (r == 1) return fail(UMI_ERR_CHAR, "Unknown character in UMI sequence");
     if (r < 0) return fail(UMI_ERR_HIP, "staging: %s", hipGetErrorString((hipError_t)(-r)));
     return UMI_OK;
 }
 
-int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits, const uint8_t *umi_ascii,
-                    const int32_t *score, uint64_t n_reads, int umi_len, int merge, uint64_t *keys, uint64_t *nmask,
-                    int32_t *freq, uint64_t *rep, uint64_t *bucket_off, uint64_t *n_entries, uint64_t *n_buckets)
+int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits, const uint8_t *d_umi_ascii,
+                           const int32_t *d_score, uint64_t n_reads, int umi_len, int merge, uint64_t *d_keys,
+                           uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
+                           uint64_t *n_entries, uint64_t *n_buckets, void *hip_stream)
+{
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    return umi_stage_reads_wide_device(ctx, d_align_key, align_key_bits, d_umi_ascii, d_score, n_reads, umi_len, 1, merge,
+                                       d_keys, d_nmask, d_freq, d_rep, d_bucket_off, n_entries, n_buckets, hip_stream);
+}
+
+int umi_stage_reads_wide(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits, const uint8_t *umi_ascii,
+                         const int32_t *score, uint64_t n_reads, int umi_len, int n_words, int merge, uint64_t *keys,
+                         uint64_t *nmask, int32_t *freq, uint64_t *rep, uint64_t *bucket_off, uint64_t *n_entries,
+                         uint64_t *n_buckets)
 {
     if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
     if (!ctx->subs.empty()) ctx = ctx->subs[0];
     if (!n_entries || !n_buckets || !bucket_off) return fail(UMI_ERR_ARG, "n_entries / n_buckets / bucket_off is NULL");
     if (n_reads && (!align_key || !umi_ascii || !keys || !freq || !rep)) return fail(UMI_ERR_ARG, "a required pointer is NULL");
-    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    if (umi_len < 1 || umi_len > UMI_MAX_WIDE_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_WIDE_UMI_LEN);
+    if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
     if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
-    const size_t n = (size_t)n_reads, m = std::max<size_t>(n, 1);
+    const size_t n = (size_t)n_reads, m = std::max<size_t>(n, 1), kw = 8 * (size_t)n_words;
     if ((rc = ctx->st_align.reserve(m * 8)) || (rc = ctx->st_umi.reserve(m * (size_t)umi_len)) ||
-        (rc = ctx->st_score.reserve(m * 4)) || (rc = ctx->st_keys.reserve(m * 8)) || (rc = ctx->st_nmask.reserve(m * 8)) ||
+        (rc = ctx->st_score.reserve(m * 4)) || (rc = ctx->st_keys.reserve(m * kw)) || (rc = ctx->st_nmask.reserve(m * kw)) ||
         (rc = ctx->st_freq.reserve(m * 4)) || (rc = ctx->st_rep.reserve(m * 8)) || (rc = ctx->st_boff.reserve((m + 1) * 8)))
         return rc;
     hipStream_t s = ctx->own_stream;
@@ -1989,21 +2029,31 @@ int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits,
         HIP_TRY(hipMemcpyAsync(ctx->st_umi.p, umi_ascii, n * (size_t)umi_len, hipMemcpyHostToDevice, s));
         if (score) HIP_TRY(hipMemcpyAsync(ctx->st_score.p, score, n * 4, hipMemcpyHostToDevice, s));
     }
-    if ((rc = umi_stage_reads_device(ctx, ctx->st_align.as<uint64_t>(), align_key_bits, ctx->st_umi.as<uint8_t>(),
-                                     score ? ctx->st_score.as<int32_t>() : nullptr, n_reads, umi_len, merge,
-                                     ctx->st_keys.as<uint64_t>(), ctx->st_nmask.as<uint64_t>(), ctx->st_freq.as<int32_t>(),
-                                     ctx->st_rep.as<uint64_t>(), ctx->st_boff.as<uint64_t>(), n_entries, n_buckets, s)))
+    if ((rc = umi_stage_reads_wide_device(ctx, ctx->st_align.as<uint64_t>(), align_key_bits, ctx->st_umi.as<uint8_t>(),
+                                          score ? ctx->st_score.as<int32_t>() : nullptr, n_reads, umi_len, n_words, merge,
+                                          ctx->st_keys.as<uint64_t>(), ctx->st_nmask.as<uint64_t>(),
+                                          ctx->st_freq.as<int32_t>(), ctx->st_rep.as<uint64_t>(),
+                                          ctx->st_boff.as<uint64_t>(), n_entries, n_buckets, s)))
         return rc;
     const size_t e = (size_t)*n_entries, b = (size_t)*n_buckets;
     if (e) {
-        HIP_TRY(hipMemcpyAsync(keys, ctx->st_keys.p, e * 8, hipMemcpyDeviceToHost, s));
-        if (nmask) HIP_TRY(hipMemcpyAsync(nmask, ctx->st_nmask.p, e * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(keys, ctx->st_keys.p, e * kw, hipMemcpyDeviceToHost, s));
+        if (nmask) HIP_TRY(hipMemcpyAsync(nmask, ctx->st_nmask.p, e * kw, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(freq, ctx->st_freq.p, e * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(rep, ctx->st_rep.p, e * 8, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipMemcpyAsync(bucket_off, ctx->st_boff.p, (b + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return UMI_OK;
+}
+
+int umi_stage_reads(umi_ctx *ctx, const uint64_t *align_key, int align_key_bits, const uint8_t *umi_ascii,
+                    const int32_t *score, uint64_t n_reads, int umi_len, int merge, uint64_t *keys, uint64_t *nmask,
+                    int32_t *freq, uint64_t *rep, uint64_t *bucket_off, uint64_t *n_entries, uint64_t *n_buckets)
+{
+    if (umi_len < 1 || umi_len > UMI_MAX_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_UMI_LEN);
+    return umi_stage_reads_wide(ctx, align_key, align_key_bits, umi_ascii, score, n_reads, umi_len, 1, merge, keys, nmask,
+                                freq, rep, bucket_off, n_entries, n_buckets);
 }
 
 int umi_encode_umis(const uint8_t *ascii, uint64_t n, int umi_len, uint64_t *keys, uint64_t *nmask)
@@ -2067,6 +2117,105 @@ int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uin
                         k, percentage,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
                         adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats, d_bucket_off);
+}
+
+int umi_dedup_batch_device_multi(umi_ctx *ctx, const uint64_t *const *d_keys, const uint64_t *const *d_nmask,
+                                 const int32_t *const *d_freq, const uint64_t *const *bucket_off,
+                                 const uint64_t *n_buckets, int umi_len, int k, float percentage, int algo,
+                                 int32_t adj_max_freq, uint8_t *const *d_kept, uint32_t *const *d_root,
+                                 uint8_t *const *d_mask_bits_all, uint64_t slice_bytes, umi_stats *stats)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (ctx->subs.empty()) return fail(UMI_ERR_ARG, "a multi-device context is needed (umi_ctx_create_multi; one device will do)");
+    const uint32_t n_dev = (uint32_t)ctx->subs.size();
+    if (!d_keys || !d_freq || !bucket_off || !n_buckets || !d_kept) return fail(UMI_ERR_ARG, "a required array of pointers is NULL");
+    for (uint32_t r = 0; r < n_dev; r++)
+        for (uint32_t q = 0; q < r; q++)
+            if (d_mask_bits_all && ctx->subs[r]->device == ctx->subs[q]->device)
+                return fail(UMI_ERR_ARG, "device %d is named twice: RCCL wants one rank per device", ctx->subs[r]->device);
+    std::vector<uint64_t> n(n_dev, 0);
+    for (uint32_t r = 0; r < n_dev; r++) {
+        int rc = check_common(ctx->subs[r], bucket_off[r], n_buckets[r], umi_len, k, algo, &n[r]);
+        if (rc) return rc;
+        if (n[r] && (!d_keys[r] || !d_freq[r] || !d_kept[r])) return fail(UMI_ERR_ARG, "device %u: keys/freq/kept is NULL", r);
+        if (d_mask_bits_all && (!d_mask_bits_all[r] || slice_bytes < (n[r] + 7) / 8))
+            return fail(UMI_ERR_ARG, "device %u: the gathered mask needs %u slices of at least %llu bytes", r, n_dev,
+                        (unsigned long long)((n[r] + 7) / 8));
+    }
+    // the communicators, once per context
+    if (d_mask_bits_all && ctx->comms.empty()) {
+        if (!ctx->rccl.load()) return fail(UMI_ERR_HIP, "%s", ctx->rccl.error.c_str());
+        std::vector<int> ids;
+        for (umi_ctx *sub : ctx->subs) ids.push_back(sub->device);
+        ctx->comms.assign(n_dev, nullptr);
+        const ncclResult_t e = ctx->rccl.CommInitAll(ctx->comms.data(), (int)n_dev, ids.data());
+        if (e != ncclSuccess) {
+            ctx->comms.clear();
+            return fail(UMI_ERR_HIP, "ncclCommInitAll: %s", ctx->rccl.GetErrorString(e));
+        }
+    }
+    // every device's shard through the ordinary pipeline on its own stream (a host thread each: the
+    // pipeline plans and synchronises), its mask packed to bits into its slot of its gather buffer
+    const int mode = algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY;
+    std::vector<ShardResult> res(n_dev);
+    std::vector<std::thread> pool;
+    for (uint32_t r = 0; r < n_dev; r++)
+        pool.emplace_back([&, r] {
+            umi_ctx *sub = ctx->subs[r];
+            ShardResult &out = res[r];
+            memset(&out.st, 0, sizeof(out.st));
+            out.st.n_buckets = n_buckets[r];
+            hipError_t e = hipSetDevice(sub->device);
+            int rc = UMI_OK;
+            if (e == hipSuccess && n[r])
+                rc = run_pipeline(sub, d_keys[r], d_nmask ? d_nmask[r] : nullptr, d_freq[r], bucket_off[r], n_buckets[r],
+                                  (uint32_t)n[r], umi_len, k, percentage, mode, adj_max_freq, d_kept[r],
+                                  d_root ? d_root[r] : nullptr, sub->own_stream, &out.st);
+            if (rc == UMI_OK && e == hipSuccess && d_mask_bits_all) {
+                uint8_t *slot = d_mask_bits_all[r] + (size_t)r * slice_bytes;
+                e = hipMemsetAsync(slot, 0, slice_bytes, sub->own_stream);
+                if (e == hipSuccess && n[r]) e = launch_pack_mask(d_kept[r], n[r], slot, sub->own_stream);
+            }
+            if (rc) {
+                out.rc = rc;
+                out.err = umi_last_error();
+            } else if (e != hipSuccess) {
+                out.rc = UMI_ERR_HIP;
+                out.err = hipGetErrorString(e);
+            }
+        });
+    for (auto &t : pool) t.join();
+    for (uint32_t r = 0; r < n_dev; r++)
+        if (res[r].rc) return fail(res[r].rc, "device %d: %s", ctx->subs[r]->device, res[r].err.c_str());
+    // the all-gatherv of the kept mask: every device's slice to every device over RCCL / xGMI, as
+    // padded slices in place (a device's send buffer is its own slot of its receive buffer) --
+    // <= 1 bit per unique UMI, latency-bound; one group, so the ranks of this one process progress together
+    if (d_mask_bits_all) {
+        ncclResult_t e = ctx->rccl.GroupStart();
+        for (uint32_t r = 0; r < n_dev && e == ncclSuccess; r++)
+            e = ctx->rccl.AllGather(d_mask_bits_all[r] + (size_t)r * slice_bytes, d_mask_bits_all[r], slice_bytes, ncclUint8,
+                                    ctx->comms[r], ctx->subs[r]->own_stream);
+        const ncclResult_t e2 = ctx->rccl.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess)
+            return fail(UMI_ERR_HIP, "ncclAllGather: %s", ctx->rccl.GetErrorString(e != ncclSuccess ? e : e2));
+        for (uint32_t r = 0; r < n_dev; r++) {
+            HIP_TRY(hipSetDevice(ctx->subs[r]->device));
+            HIP_TRY(hipStreamSynchronize(ctx->subs[r]->own_stream));
+        }
+    }
+    if (stats) {
+        umi_stats total = res[0].st;
+        total.n_umis = n[0];
+        for (uint32_t r = 1; r < n_dev; r++) {
+            merge_stats(total, res[r].st);
+            total.max_bucket = std::max(total.max_bucket, res[r].st.max_bucket);
+            total.n_pairs += res[r].st.n_pairs;
+            total.n_umis += n[r];
+            total.n_buckets += n_buckets[r];
+        }
+        *stats = total;
+    }
+    return UMI_OK;
 }
 
 int umi_pairs_partial_device(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,

@@ -46,13 +46,8 @@ enum Counter : int {
 // The flags of the collapse rounds ("round r changed a label") sit behind the counters in the
 // same device block, so that one memset clears and one copy reads everything the host looks at.
 constexpr int MAX_ROUNDS_PER_SYNC = 16; // rounds enqueued between two host checks
-// ... and behind the flags the words of the fused collapse kernel: [0] barrier arrivals, [1] "gave
-// up" (a barrier was not passed in time: the host runs the phases as separate launches), [2] one-way
-// rounds it ran, [3] one-way pairs it found in the pair kernel's private slots
-constexpr int COLLAPSE_SYNC_WORDS = 4;
 constexpr size_t CTRL_FLAGS_OFF = CNT_COUNT * sizeof(unsigned long long);
-constexpr size_t CTRL_SYNC_OFF = CTRL_FLAGS_OFF + (MAX_ROUNDS_PER_SYNC + 1) * sizeof(uint32_t);
-constexpr size_t CTRL_BYTES = (CTRL_SYNC_OFF + COLLAPSE_SYNC_WORDS * sizeof(uint32_t) + 255) & ~(size_t)255; // (one fill kernel: a whole number of 16-byte words)
+constexpr size_t CTRL_BYTES = (CTRL_FLAGS_OFF + (MAX_ROUNDS_PER_SYNC + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; // (one fill kernel: a whole number of 16-byte words)
 
 // Bit-sliced kernel: one block works on rows [bucket_start + 32*group0, ...) of one
 // bucket (256*G or 64*G groups of 32 rows, see BS_* below) against columns [col0, col1).
@@ -279,15 +274,24 @@ hipError_t launch_seg_edge_append(const PairArgs &a, const SegArgs &g, uint32_t 
 hipError_t launch_wide_pairs(const PairArgs &a, uint32_t n_tasks, int n_words, hipStream_t s);
 
 // ---- read staging on the device (umihip_stage.hip) ----
-size_t stage_workspace_bytes(uint32_t n_reads);
+size_t stage_workspace_bytes(uint32_t n_reads, int n_words);
 // reads (alignment key, UMI text, score) -> entries in canonical order + bucket table, all device
-// memory; h_pinned4: four pinned 64-bit words for the counts the host needs on the way.
-// 0 ok; 1 a character outside ATCGN; negative: -(hipError_t)
+// memory (keys / nmask: n_words words per entry); h_pinned4: four pinned 64-bit words for the counts
+// the host needs on the way.  0 ok; 1 a character outside ATCGN; negative: -(hipError_t)
 int stage_reads_on_device(void *workspace, const uint64_t *d_align, int align_bits, const uint8_t *d_umi,
-                          const int32_t *d_score, uint32_t n, int umi_len, int merge, uint64_t *d_keys,
+                          const int32_t *d_score, uint32_t n, int umi_len, int n_words, int merge, uint64_t *d_keys,
                           uint64_t *d_nmask, int32_t *d_freq, uint64_t *d_rep, uint64_t *d_bucket_off,
                           uint64_t *n_entries_out, uint64_t *n_buckets_out, unsigned long long *h_pinned4,
                           hipStream_t s);
+
+// ---- sort and scan primitives of the staging (umihip_radix.hip) ----
+size_t radix_sort_temp_bytes(uint32_t n);
+// stable sort of (key, value) pairs by bits [begin_bit, end_bit) of the key; the buffers are used in
+// turn, *result_in_b says where the result lies
+hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s);
+size_t scan_temp_bytes(uint32_t n);
+hipError_t scan_inclusive_u64(const uint64_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes, hipStream_t s);
 
 // ---- directional collapse by union-find (umihip_collapse.hip) ----
 // comp[] (= label[], identity on entry) becomes the smallest index of each entry's set under the
@@ -305,29 +309,16 @@ struct CollapseDesc {
     uint32_t *parent, *lab;  // label[] (the union-find forest of the symmetric pairs) and lab[]
     const uint2 *edges;      // the list
     uint32_t edge_cap;
-    const uint2 *priv_edges; // the pair kernel's private slots (null: everything is in the list)
-    const uint32_t *priv_cnt;
-    uint32_t n_slots;
     const RangeTask *ranges; // entries the fused small-bucket kernel left (null: all n)
     uint32_t n_ranges, n;
     uint8_t *kept;
     uint32_t *root;
     unsigned long long *counters;
-    uint32_t *changed, *sync; // the flags and sync words of the control block
-    uint32_t *flags;          // [COLLAPSE_BARRIER_WORDS] the fused kernel's barrier: a flag word per block, then the arrival
-                              // counters (a line each; zero at creation, left zero by every barrier that was passed)
-    uint32_t epoch;           // grows by COLLAPSE_EPOCH_STEP per launch: a barrier's number is epoch + its index
+    uint32_t *changed;       // the rounds' flags in the control block
 };
-constexpr uint32_t COLLAPSE_MAX_GRID = 2048, COLLAPSE_EPOCH_STEP = 64;
-constexpr uint32_t COLLAPSE_GROUP_WORDS = COLLAPSE_MAX_GRID / 32; // a counter per group of 32 blocks
-constexpr uint32_t COLLAPSE_LINE_WORDS = 16;                      // one 64-byte line per flag and counter
-constexpr size_t COLLAPSE_BARRIER_WORDS = (size_t)(COLLAPSE_MAX_GRID + COLLAPSE_GROUP_WORDS + 1) * COLLAPSE_LINE_WORDS;
-// ... in one launch (flatten, one-way rounds until one is quiet, kept / root / survivor count; grid
-// barriers in between) ...
-hipError_t launch_collapse_fused(const CollapseDesc &d, uint32_t n_cus, hipStream_t s);
 // bytes (a multiple of 8) of the control block to its pinned, device-visible host mirror
 hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes, hipStream_t s);
-// ... and phase by phase: comp[v] = root of v in place and lab[v] = v; round `round` along the
+// ... phase by phase: comp[v] = root of v in place and lab[v] = v; round `round` along the
 // one-way pairs (a no-op once round - 1 was quiet); label = lab[comp[v]], kept, root, survivors
 hipError_t launch_collapse_flatten(const CollapseDesc &d, hipStream_t s);
 hipError_t launch_collapse_round(const CollapseDesc &d, int round, hipStream_t s);

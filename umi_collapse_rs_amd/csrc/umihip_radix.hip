@@ -1,0 +1,338 @@
+// Sort and scan primitives of the read staging (gfx950): a stable least-significant-digit radix
+// sort of (64-bit key, 32-bit value) pairs with one read and one write of the data per 8-bit digit
+// -- tiles chained by a decoupled look-back, as in the segment index's bin scan -- and a single-pass
+// inclusive scan of 64-bit words (two 32-bit counters ride in one word).
+//
+// What they serve in the reference (tkob-vh/umi-collapse-rs): the two HashMaps of
+// DeduplicateSAM::deduplicate_and_merge (src/deduplicate_sam.rs:88-89,148-176) group the reads by
+// alignment and by UMI; here the reads are sorted by (alignment key, UMI) instead and equal
+// neighbours are one entry (umihip_stage.hip).  Integer / byte work on HBM streams, no MFMA.
+//
+// One pass over a tile of 4,096 pairs (256 threads, 16 rounds of 64 pairs per wave):
+//   rank   every key's position among the keys of its digit inside its wave's 1,024 pairs, in
+//          order: the lanes of a round that share a digit find each other with eight ballots (one
+//          per bit of the digit), the wave keeps a running count per digit in LDS;
+//   chain  the tile's 256 counts are published, thread d adds up digit d's counts of the tiles before
+//          (stopping at the first tile that knows its own prefix) and publishes the tile's prefix --
+//          tiles draw their number from a ticket counter, so everything before a tile is running;
+//   move   the pairs go to LDS in digit order and from there to their places: a digit's pairs of
+//          one tile are neighbours in the output, the stores of a wave fill whole lines.
+// The digit histograms of all passes -- what tile 0's prefix starts from -- come from one sweep over
+// the keys in front of the first pass.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+
+#include "umihip_internal.h"
+
+namespace umihip {
+
+namespace {
+
+constexpr int RS_THREADS = 256, RS_ROUNDS = 16, RS_TILE = RS_THREADS * RS_ROUNDS, RS_RADIX = 256, RS_WAVES = RS_THREADS / 64;
+constexpr int RS_MAX_PASSES = 8;
+constexpr unsigned long long RS_HAVE = 1ull << 62, RS_PREFIX = 1ull << 63, RS_COUNT = (1ull << 62) - 1ull;
+
+struct RadixPass {
+    const uint64_t *kin;
+    uint64_t *kout;
+    const uint32_t *vin;
+    uint32_t *vout;
+    uint32_t n;
+    int shift;
+    uint32_t mask;
+    const uint32_t *digit_base;   // [256] keys of the whole input with a smaller digit
+    unsigned long long *status;   // [tiles][256], zero before the pass
+    uint32_t *ticket;             // zero before the pass
+};
+
+// digit histograms of all passes in one sweep
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int begin_bit,
+                                                         int n_passes, int end_bit, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
+    for (int i = threadIdx.x; i < n_passes * RS_RADIX; i += blockDim.x) (&h[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < n_passes; p++) {
+            const int sh = begin_bit + 8 * p, bits = std::min(8, end_bit - sh);
+            atomicAdd(&h[p][(uint32_t)(k >> sh) & ((1u << bits) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_passes * RS_RADIX; i += blockDim.x) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// exclusive scan of a pass's 256 bins, in place (one block per pass)
+__global__ __launch_bounds__(RS_RADIX) void radix_base_kernel(uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t wsum[RS_RADIX / 64];
+    uint32_t *h = hist + (size_t)blockIdx.x * RS_RADIX;
+    const uint32_t v = h[threadIdx.x];
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += wsum[w];
+    h[threadIdx.x] = off + incl - v;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
+{
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t cnt[RS_WAVES][RS_RADIX]; // per wave: running count of every digit, then the wave's offset in the tile's run
+    __shared__ uint32_t tile_start[RS_RADIX];    // first position of digit d in the tile's digit order
+    __shared__ uint32_t gbase[RS_RADIX];         // output position of that first pair, less tile_start[d]
+    __shared__ uint32_t wtot[RS_WAVES];
+    __shared__ uint64_t skeys[RS_TILE];
+    __shared__ uint32_t svals[RS_TILE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t base = (uint64_t)tile * RS_TILE;
+    const uint32_t tile_n = (uint32_t)std::min<uint64_t>(RS_TILE, a.n - base);
+    // ---- rank: the wave's 1,024 pairs in 16 rounds of 64 consecutive ones
+    uint64_t key[RS_ROUNDS];
+    uint32_t val[RS_ROUNDS], rank[RS_ROUNDS];
+    volatile uint32_t *my_cnt = cnt[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const uint32_t at = (uint32_t)wave * (RS_ROUNDS * 64) + (uint32_t)r * 64 + (uint32_t)lane;
+        const bool valid = at < tile_n;
+        key[r] = valid ? a.kin[base + at] : ~0ull;
+        val[r] = valid ? a.vin[base + at] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const uint32_t at = (uint32_t)wave * (RS_ROUNDS * 64) + (uint32_t)r * 64 + (uint32_t)lane;
+        const bool valid = at < tile_n;
+        const uint32_t d = (uint32_t)(key[r] >> a.shift) & a.mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t pre = my_cnt[d];
+        rank[r] = pre + (uint32_t)__builtin_popcountll(peers & lt);
+        if (valid && (peers & lt) == 0ull) my_cnt[d] = pre + (uint32_t)__builtin_popcountll(peers); // (the first of its peers)
+    }
+    __syncthreads();
+    // ---- chain: thread d owns digit d
+    {
+        const int d = tid;
+        uint32_t c[RS_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) {
+            c[w] = cnt[w][d];
+            cnt[w][d] = tot; // the wave's offset inside the tile's run of digit d
+            tot += c[w];
+        }
+        // tile_start: exclusive scan of tot over the digits
+        uint32_t incl = tot;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; w++) off += wtot[w];
+        const uint32_t start = off + incl - tot;
+        tile_start[d] = start;
+        unsigned long long *st = a.status + (size_t)tile * RS_RADIX + d;
+        unsigned long long before = 0;
+        if (tile == 0) {
+            __hip_atomic_store(st, RS_HAVE | RS_PREFIX | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(st, RS_HAVE | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) { // (tile t drew its ticket before this one: it is running)
+                unsigned long long v;
+                do v = __hip_atomic_load(a.status + (size_t)t * RS_RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (!(v & RS_HAVE));
+                before += v & RS_COUNT;
+                if (v & RS_PREFIX) break;
+            }
+            __hip_atomic_store(st, RS_HAVE | RS_PREFIX | (before + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gbase[d] = a.digit_base[d] + (uint32_t)before - start;
+    }
+    __syncthreads();
+    // ---- move: to LDS in digit order, then out in runs
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const uint32_t at = (uint32_t)wave * (RS_ROUNDS * 64) + (uint32_t)r * 64 + (uint32_t)lane;
+        if (at < tile_n) {
+            const uint32_t d = (uint32_t)(key[r] >> a.shift) & a.mask;
+            const uint32_t pos = tile_start[d] + cnt[wave][d] + rank[r];
+            skeys[pos] = key[r];
+            svals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < tile_n; i += RS_THREADS) {
+        const uint64_t k = skeys[i];
+        const uint32_t d = (uint32_t)(k >> a.shift) & a.mask;
+        const uint32_t pos = gbase[d] + i;
+        a.kout[pos] = k;
+        a.vout[pos] = svals[i];
+    }
+}
+
+// ---- inclusive scan of 64-bit words, one pass: tiles of 2,048 words chained by look-back
+constexpr int SC_THREADS = 256, SC_ITEMS = 8, SC_TILE = SC_THREADS * SC_ITEMS;
+// status: two words per tile (sum, flag) would tear; a scan value can use all 64 bits, so the flag
+// sits in a word of its own and the value is published BEFORE the flag (release / acquire)
+__global__ __launch_bounds__(SC_THREADS) void scan_u64_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                              uint32_t n, unsigned long long *agg, unsigned long long *pre,
+                                                              uint32_t *flag, uint32_t *ticket)
+{
+    __shared__ uint32_t s_tile;
+    __shared__ uint64_t wsum[SC_THREADS / 64];
+    __shared__ uint64_t s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t base = (uint64_t)tile * SC_TILE + (uint64_t)tid * SC_ITEMS;
+    uint64_t v[SC_ITEMS], mine = 0;
+#pragma unroll
+    for (int q = 0; q < SC_ITEMS; q++) {
+        v[q] = base + q < n ? in[base + q] : 0ull;
+        mine += v[q];
+    }
+    uint64_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+    for (int w = 0; w < SC_THREADS / 64; w++) {
+        if (w < wave) off += wsum[w];
+        tot += wsum[w];
+    }
+    if (tid == 0) {
+        uint64_t before = 0;
+        if (tile == 0) {
+            __hip_atomic_store(&pre[0], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&flag[0], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&agg[tile], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&flag[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
+                uint32_t f;
+                do f = __hip_atomic_load(&flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while (f == 0u);
+                // (a tile's flag goes 1 -> 2; its prefix is written before the 2)
+                if (f == 2u) {
+                    before += __hip_atomic_load(&pre[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                before += __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&pre[tile], before + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&flag[tile], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_before = before;
+    }
+    __syncthreads();
+    uint64_t run = s_before + off + incl - mine;
+#pragma unroll
+    for (int q = 0; q < SC_ITEMS; q++) {
+        run += v[q];
+        if (base + q < n) out[base + q] = run;
+    }
+}
+
+inline uint32_t tiles_of(uint32_t n, uint32_t tile) { return std::max(1u, (uint32_t)(((uint64_t)n + tile - 1) / tile)); }
+
+struct RadixTemp {
+    uint32_t *hist;             // [RS_MAX_PASSES][256]
+    uint32_t *tickets;          // [RS_MAX_PASSES + 1]
+    unsigned long long *status; // [passes][tiles][256]
+    size_t zero_bytes, total;
+};
+RadixTemp radix_carve(void *temp, uint32_t n, int passes)
+{
+    RadixTemp t;
+    char *p = (char *)temp;
+    size_t off = 0;
+    t.hist = (uint32_t *)(p + off);
+    off += (size_t)RS_MAX_PASSES * RS_RADIX * 4;
+    t.tickets = (uint32_t *)(p + off);
+    off += 64;
+    t.status = (unsigned long long *)(p + off);
+    off += (size_t)passes * tiles_of(n, RS_TILE) * RS_RADIX * 8;
+    t.zero_bytes = t.total = (off + 255) & ~(size_t)255;
+    return t;
+}
+
+} // namespace
+
+size_t radix_sort_temp_bytes(uint32_t n) { return radix_carve(nullptr, n, RS_MAX_PASSES).total; }
+
+hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s)
+{
+    *result_in_b = false;
+    if (n == 0 || end_bit <= begin_bit) return hipSuccess;
+    if (begin_bit < 0 || end_bit > 64) return hipErrorInvalidValue;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    const RadixTemp t = radix_carve(temp, n, passes);
+    if (t.total > temp_bytes) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(temp, 0, t.zero_bytes, s);
+    if (e != hipSuccess) return e;
+    const uint32_t tiles = tiles_of(n, RS_TILE);
+    radix_hist_kernel<<<std::min(tiles_of(n, 256 * 16), 2048u), 256, 0, s>>>(keys_a, n, begin_bit, passes, end_bit, t.hist);
+    radix_base_kernel<<<passes, RS_RADIX, 0, s>>>(t.hist);
+    uint64_t *kin = keys_a, *kout = keys_b;
+    uint32_t *vin = vals_a, *vout = vals_b;
+    for (int p = 0; p < passes; p++) {
+        RadixPass a;
+        a.kin = kin;
+        a.kout = kout;
+        a.vin = vin;
+        a.vout = vout;
+        a.n = n;
+        a.shift = begin_bit + 8 * p;
+        a.mask = (1u << std::min(8, end_bit - a.shift)) - 1u;
+        a.digit_base = t.hist + (size_t)p * RS_RADIX;
+        a.status = t.status + (size_t)p * tiles * RS_RADIX;
+        a.ticket = t.tickets + p;
+        radix_onesweep_kernel<<<tiles, RS_THREADS, 0, s>>>(a);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    *result_in_b = (passes & 1) != 0;
+    return hipGetLastError();
+}
+
+size_t scan_temp_bytes(uint32_t n) { return ((size_t)tiles_of(n, SC_TILE) * 20 + 64 + 255) & ~(size_t)255; }
+
+hipError_t scan_inclusive_u64(const uint64_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t tiles = tiles_of(n, SC_TILE);
+    if (scan_temp_bytes(n) > temp_bytes) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(temp, 0, scan_temp_bytes(n), s);
+    if (e != hipSuccess) return e;
+    unsigned long long *agg = (unsigned long long *)temp, *pre = agg + tiles;
+    uint32_t *flag = (uint32_t *)(pre + tiles), *ticket = flag + tiles;
+    scan_u64_kernel<<<tiles, SC_THREADS, 0, s>>>(in, out, n, agg, pre, flag, ticket);
+    return hipGetLastError();
+}
+
+} // namespace umihip

@@ -46,6 +46,9 @@ struct Cli { // src/cli.rs:7-77 (same flags, same defaults)
     std::string dump_staging; // write the staged hot-path input here and stop before the GPU
     bool passthrough = false; // write every mapped record back (codec round trip), no dedup
     std::vector<int> devices{0}; // --device <ID> or --devices <ID,ID,...>
+    int compress_level = 1;      // --compress-level 0..9: deflate level of the output's BGZF blocks.  Parity is
+                                 // defined on the decompressed stream (htslib's own level and backend are
+                                 // not reproducible here), and level 1 deflates a third of level 6's time
     std::string stage = "auto";  // --stage gpu|host|auto: where the reads are merged per (position, UMI) and
                                  // put in rank order (auto: on the GPU unless --paired or --tag need the
                                  // host's per-read bookkeeping)
@@ -67,10 +70,11 @@ struct HipLib {
     int (*ctx_create_multi)(const int *, int, umi_ctx **) = nullptr;
     int (*ctx_set_option)(umi_ctx *, const char *, int64_t) = nullptr;
     const char *(*last_error)(void) = nullptr;
-    int (*stage_reads)(umi_ctx *, const uint64_t *, int, const uint8_t *, const int32_t *, uint64_t, int, int,
+    // (the forms for keys of any number of words: one word is the ordinary call behind them)
+    int (*stage_reads)(umi_ctx *, const uint64_t *, int, const uint8_t *, const int32_t *, uint64_t, int, int, int,
                        uint64_t *, uint64_t *, int32_t *, uint64_t *, uint64_t *, uint64_t *, uint64_t *) = nullptr;
-    int (*dedup_batch)(umi_ctx *, const uint64_t *, const uint64_t *, const int32_t *, const uint64_t *, uint64_t, int,
-                       int, float, int, int32_t, uint8_t *, uint32_t *, umi_stats *) = nullptr;
+    int (*dedup_batch)(umi_ctx *, const uint64_t *, const uint64_t *, int, const int32_t *, const uint64_t *, uint64_t,
+                       int, int, float, int, int32_t, uint8_t *, uint32_t *, umi_stats *) = nullptr;
     std::string error;
     bool load()
     {
@@ -93,17 +97,34 @@ struct HipLib {
         ctx_create_multi = (decltype(ctx_create_multi))sym("umi_ctx_create_multi");
         ctx_set_option = (decltype(ctx_set_option))sym("umi_ctx_set_option");
         last_error = (decltype(last_error))sym("umi_last_error");
-        stage_reads = (decltype(stage_reads))sym("umi_stage_reads");
-        dedup_batch = (decltype(dedup_batch))sym("umi_dedup_batch");
+        stage_reads = (decltype(stage_reads))sym("umi_stage_reads_wide");
+        dedup_batch = (decltype(dedup_batch))sym("umi_dedup_batch_wide");
         return error.empty();
     }
 };
 
-// src/utils/mod.rs:63-83 with the codes of src/utils/read.rs:23-31 (the library's umi_encode_umis,
-// restated here so that the staging of the host path needs no library call)
-bool encode_umi(const uint8_t *u, size_t len, uint64_t *key, uint64_t *nmask)
+// A UMI key: BitSet.bits of the reference (src/utils/bitset.rs:9-27), up to 85 bases in four words
+constexpr int MAX_WORDS = 4;
+struct UmiKey {
+    uint64_t w[MAX_WORDS];
+    bool operator==(const UmiKey &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+struct UmiKeyHash {
+    size_t operator()(const UmiKey &k) const
+    {
+        uint64_t x = k.w[0] * 0x9E3779B97F4A7C15ull ^ (k.w[1] + 0x7F4A7C15u) * 0xD6E8FEB86659FD93ull ^ (k.w[2] << 7) ^ (k.w[3] >> 3);
+        x ^= x >> 31;
+        x *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(x ^ (x >> 29));
+    }
+};
+
+// src/utils/mod.rs:63-83 with the codes of src/utils/read.rs:23-31 (the library's umi_encode_umis[_wide],
+// restated here so that the staging of the host path needs no library call); base b at bits
+// 3b .. 3b+2 of the word string, bit by bit: a base may sit across two words (bitset.rs:52-75)
+bool encode_umi(const uint8_t *u, size_t len, UmiKey *key, UmiKey *nmask)
 {
-    uint64_t k = 0, nm = 0;
+    UmiKey k{{0, 0, 0, 0}}, nm{{0, 0, 0, 0}};
     for (size_t b = 0; b < len; b++) {
         uint64_t c;
         switch (u[b]) {
@@ -111,10 +132,14 @@ bool encode_umi(const uint8_t *u, size_t len, uint64_t *key, uint64_t *nmask)
         case 'T': c = 5; break;
         case 'C': c = 6; break;
         case 'G': c = 3; break;
-        case 'N': c = 4; nm |= 7ull << (3 * b); break;
+        case 'N': c = 4; break;
         default: return false;
         }
-        k |= c << (3 * b);
+        for (int j = 0; j < 3; j++) {
+            const size_t bit = 3 * b + j;
+            if ((c >> j) & 1) k.w[bit >> 6] |= 1ull << (bit & 63);
+            if (c == 4) nm.w[bit >> 6] |= 1ull << (bit & 63);
+        }
     }
     *key = k;
     *nmask = nm;
@@ -141,6 +166,7 @@ void usage()
               "      --tag                Write every read tagged with its cluster (MI, cs, su) instead of\n"
               "                           removing duplicates\n"
               "      --two-pass           accepted and rejected (see header)\n"
+              "      --compress-level <N> deflate level of the output BAM, 0..9 [default: 1]\n"
               "      --stage <WHERE>      gpu, host or auto: where reads are merged per (position, UMI) [default: auto]\n"
               "      --device <ID>        GPU to use [default: 0]\n"
               "      --devices <ID,..>    several GPUs of the node: alignment positions are sharded over them");
@@ -184,6 +210,10 @@ Cli parse(int argc, char **argv)
         else if (a == "--dump-staging") c.dump_staging = need(i);
         else if (a == "--passthrough") c.passthrough = true;
         else if (a == "--stage") c.stage = need(i);
+        else if (a == "--compress-level") {
+            c.compress_level = std::atoi(need(i));
+            if (c.compress_level < 0 || c.compress_level > 9) die("--compress-level wants 0..9");
+        }
         else if (a == "--device") c.devices.assign(1, device_id(need(i)));
         else if (a == "--devices") { // the GPUs of the node the position buckets are sharded over
             c.devices.clear();
@@ -203,7 +233,7 @@ Cli parse(int argc, char **argv)
 }
 
 struct Entry { // one (alignment key, UMI): ReadFreq of src/utils/read_freq.rs + its key
-    uint64_t key, nmask;
+    UmiKey key, nmask;
     int32_t freq;
     int32_t score;  // avg qual or mapq of the representative
     uint32_t rep;   // record index of the representative read
@@ -302,8 +332,8 @@ int main(int argc, char **argv)
             int32_t fr[2];
             uint8_t kept[2];
             umi_stats wst;
-            if (lib.stage_reads(c, akey, 1, umis, nullptr, 2, 4, 0, k, nm, fr, rp, off, &ne, &nbk) != UMI_OK ||
-                lib.dedup_batch(c, k, nullptr, fr, off, nbk, 4, 1, 0.5f, UMI_ALGO_DIRECTIONAL, 0, kept, nullptr, &wst) != UMI_OK)
+            if (lib.stage_reads(c, akey, 1, umis, nullptr, 2, 4, 1, 0, k, nm, fr, rp, off, &ne, &nbk) != UMI_OK ||
+                lib.dedup_batch(c, k, nullptr, 1, fr, off, nbk, 4, 1, 0.5f, UMI_ALGO_DIRECTIONAL, 0, kept, nullptr, &wst) != UMI_OK)
                 warm_error = lib.last_error(); // (reported when the real call fails the same way)
             return c;
         });
@@ -350,7 +380,8 @@ int main(int argc, char **argv)
                 }
             }
         struct ReadInfo {
-            uint64_t coord, ref_strand, tlen, key, nmask;
+            uint64_t coord, ref_strand, tlen;
+            UmiKey key, nmask;
             int32_t score;
             uint8_t state; // 0 staged, 1 unmapped, 2 error, 3 second mate (not counted),
                            // 4 mate unmapped, 5 filtered (--remove-unpaired / --remove-chimeric)
@@ -380,7 +411,7 @@ int main(int argc, char **argv)
                 const size_t at = sp ? (size_t)(sp - q) + 1 : 0;
                 if (!sp) err = "failed to get the umi";
                 else if (umi_length == 0) err = "Empty UMI sequence extracted";
-                else if (umi_length > UMI_MAX_UMI_LEN) err = "UMIs of more than 21 bases are not handled by this program (the library's _wide calls take them)";
+                else if (umi_length > UMI_MAX_WIDE_UMI_LEN) err = "UMIs of more than 85 bases are not handled";
                 else if (at + umi_length > qn) err = "UMI runs past the end of the read name";
                 else if (!encode_umi(q + at, umi_length, &ii.key, &ii.nmask)) err = "Unknown character in UMI sequence"; // utils/mod.rs:77-79
                 if (err) {
@@ -416,7 +447,8 @@ int main(int argc, char **argv)
         // bookkeeping of the host version below; both give the same arrays.
         size_t n = 0, nb = 0, max_umi = 0;
         bool any_n = false;
-        std::vector<uint64_t> keys, nmask, off;
+        const int n_words = umi_length ? (int)((3 * umi_length + 63) / 64) : 1; // words per key (bitset.rs:17-18)
+        std::vector<uint64_t> keys, nmask, off; // keys / nmask: n_words words per entry
         std::vector<int32_t> freq;
         std::vector<uint32_t> rep;
         std::vector<std::vector<uint32_t>> global_of;
@@ -466,26 +498,24 @@ int main(int argc, char **argv)
             for (uint8_t f : fits) gpu_stage = gpu_stage && f;
             if (gpu_stage) {
                 need_ctx();
-                keys.assign(ns, 0); nmask.assign(ns, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
+                keys.assign(ns * n_words, 0); nmask.assign(ns * n_words, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
                 uint64_t ne = 0, nbk = 0;
-                if (lib.stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, merge != 0 ? 1 : 0,
+                if (lib.stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, n_words, merge != 0 ? 1 : 0,
                                     keys.data(), nmask.data(), freq.data(), rep64.data(), off.data(), &ne, &nbk) != UMI_OK)
                     die(lib.last_error());
                 n = (size_t)ne;
                 nb = (size_t)nbk;
-                keys.resize(n); nmask.resize(n); freq.resize(n); off.resize(nb + 1);
+                keys.resize(n * n_words); nmask.resize(n * n_words); freq.resize(n); off.resize(nb + 1);
                 rep.resize(n);
-                for (size_t i = 0; i < n; i++) {
-                    rep[i] = staged[rep64[i]];
-                    any_n |= nmask[i] != 0;
-                }
+                for (size_t i = 0; i < n; i++) rep[i] = staged[rep64[i]];
+                for (uint64_t m : nmask) any_n |= m != 0;
                 for (size_t b = 0; b < nb; b++) max_umi = std::max<size_t>(max_umi, off[b + 1] - off[b]);
             }
         }
         if (!gpu_stage) {
         struct Shard {
             std::unordered_map<AlignKey, uint32_t, KeyHash> bucket_of; // Align -> local bucket
-            std::vector<std::unordered_map<uint64_t, uint32_t>> umi_index;                     // key -> local entry
+            std::vector<std::unordered_map<UmiKey, uint32_t, UmiKeyHash>> umi_index;          // key -> local entry
             std::vector<std::vector<uint32_t>> bucket_entries;
             std::vector<uint32_t> bucket_first; // first read of the bucket
             std::vector<Entry> entries;
@@ -537,7 +567,7 @@ int main(int argc, char **argv)
         }
         std::sort(order.begin(), order.end(), [](const BucketRef &x, const BucketRef &y) { return x.first < y.first; });
         nb = order.size();
-        keys.assign(n, 0); nmask.assign(n, 0); off.assign(nb + 1, 0);
+        keys.assign(n * n_words, 0); nmask.assign(n * n_words, 0); off.assign(nb + 1, 0);
         freq.assign(n, 0);
         rep.assign(n, 0);
         size_t w = 0;
@@ -550,8 +580,12 @@ int main(int argc, char **argv)
             for (uint32_t ei : v) {
                 const Entry &en = sh.entries[ei];
                 if (args.track_clusters) global_of[order[b].shard][ei] = (uint32_t)w;
-                keys[w] = en.key; nmask[w] = en.nmask; freq[w] = en.freq; rep[w] = en.rep;
-                any_n |= en.nmask != 0;
+                for (int q = 0; q < n_words; q++) {
+                    keys[w * n_words + q] = en.key.w[q];
+                    nmask[w * n_words + q] = en.nmask.w[q];
+                    any_n |= en.nmask.w[q] != 0;
+                }
+                freq[w] = en.freq; rep[w] = en.rep;
                 w++;
             }
             off[b + 1] = w;
@@ -563,9 +597,9 @@ int main(int argc, char **argv)
         if (!args.dump_staging.empty()) { // test hook: staged hot-path input, no GPU touched
             FILE *f = std::fopen(args.dump_staging.c_str(), "wb");
             if (!f) die("cannot open " + args.dump_staging);
-            const uint64_t hdr[4] = {n, nb, umi_length, 0};
+            const uint64_t hdr[4] = {n, nb, umi_length, (uint64_t)n_words};
             std::fwrite(hdr, 8, 4, f);
-            std::fwrite(keys.data(), 8, n, f); std::fwrite(nmask.data(), 8, n, f);
+            std::fwrite(keys.data(), 8, n * n_words, f); std::fwrite(nmask.data(), 8, n * n_words, f);
             std::fwrite(freq.data(), 4, n, f); std::fwrite(rep.data(), 4, n, f);
             std::fwrite(off.data(), 8, nb + 1, f);
             std::fclose(f);
@@ -583,7 +617,7 @@ int main(int argc, char **argv)
             // The reference accepts every --data value and always runs Naive
             // (deduplicate_sam.rs:210-213): the result -- and here the path -- is the same for all of them.
             t_gpu0 = now_s();
-            if (lib.dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, freq.data(), off.data(), nb,
+            if (lib.dedup_batch(ctx, keys.data(), any_n ? nmask.data() : nullptr, n_words, freq.data(), off.data(), nb,
                                 (int)umi_length, args.k, args.percentage, algo, 0 /* adjacency.rs:56 */,
                                 kept.data(), args.track_clusters ? root.data() : nullptr, &st) != UMI_OK)
                 die(lib.last_error());
@@ -687,7 +721,7 @@ int main(int argc, char **argv)
                 o += 4;
             }
         }
-        umi::bgzf::compress_to_file(args.output, out.data(), out.size(), args.num_threads);
+        umi::bgzf::compress_to_file(args.output, out.data(), out.size(), args.num_threads, args.compress_level);
         const double t_end = now_s();
 
         // counters of deduplicate_sam.rs:243-268

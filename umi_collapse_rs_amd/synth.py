@@ -30,6 +30,23 @@ def bases_to_keys(b2):
     return keys
 
 
+def bases_to_keys_wide(b2):
+    """b2: uint8 [n, L] base ids 0..3 -> BitSet.bits as uint64 [n, ceil(3 L / 64)] (base i at bits
+    3i .. 3i+2 of the word string, a base may sit across two words: src/utils/bitset.rs:17-27,52-61)."""
+    n, L = b2.shape
+    w = (3 * L + 63) // 64
+    keys = np.zeros((n, w), dtype=np.uint64)
+    for i in range(L):
+        code = _CODE3[b2[:, i]]
+        bit = 3 * i
+        wi, sh = bit >> 6, bit & 63
+        with np.errstate(over="ignore"):
+            keys[:, wi] |= code << np.uint64(sh)
+            if sh > 61 and wi + 1 < w:
+                keys[:, wi + 1] |= code >> np.uint64(64 - sh)
+    return keys
+
+
 def uniform_reads(seed, n_reads, umi_len, start=0):
     """Uniform-random UMIs (the single-position variant of config 2): base ids [n, L]."""
     idx = np.arange(start, start + n_reads, dtype=np.uint64)
@@ -87,10 +104,16 @@ def stage(pos, keys):
     brank = np.empty(len(upos), dtype=np.int64)
     brank[np.argsort(pfirst, kind="stable")] = np.arange(len(upos))
     bucket = brank[pinv]
-    order = np.lexsort((keys, bucket))  # stable: equal (bucket,key) keep read order
-    sb, sk = bucket[order], keys[order]
-    new = np.ones(n, dtype=bool)
-    new[1:] = (sb[1:] != sb[:-1]) | (sk[1:] != sk[:-1])
+    if keys.ndim == 2:  # keys of several words (umi_len > 21): rows compare word by word
+        order = np.lexsort(tuple(keys[:, w] for w in range(keys.shape[1])) + (bucket,))
+        sb, sk = bucket[order], keys[order]
+        new = np.ones(n, dtype=bool)
+        new[1:] = (sb[1:] != sb[:-1]) | (sk[1:] != sk[:-1]).any(axis=1)
+    else:
+        order = np.lexsort((keys, bucket))  # stable: equal (bucket,key) keep read order
+        sb, sk = bucket[order], keys[order]
+        new = np.ones(n, dtype=bool)
+        new[1:] = (sb[1:] != sb[:-1]) | (sk[1:] != sk[:-1])
     starts = np.nonzero(new)[0]
     ukeys, ubucket, first = sk[starts], sb[starts], order[starts]
     freq = np.diff(np.append(starts, n)).astype(np.int64)
@@ -150,7 +173,7 @@ def config2m(seed=22, n_reads=1_000_000, umi_len=12, n_molecules=100_000, err=0.
     shift = rng.integers(1, 4, bases.shape, dtype=np.uint8)
     bases = np.where(mut, (bases + shift) & 3, bases).astype(np.uint8)
     bases = bases[rng.permutation(n_reads)]  # first-appearance order is not molecule order
-    st = stage(np.zeros(n_reads, dtype=np.int64), bases_to_keys(bases))
+    st = stage(np.zeros(n_reads, dtype=np.int64), bases_to_keys(bases) if umi_len <= 21 else bases_to_keys_wide(bases))
     st["n_reads"] = n_reads
     st["n_molecules"] = int(mol_of.max()) + 1
     return st
