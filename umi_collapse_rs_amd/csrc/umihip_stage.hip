@@ -57,13 +57,22 @@ __global__ __launch_bounds__(256) void stage_encode_kernel(const uint8_t *__rest
                                                            unsigned long long *__restrict__ counters)
 {
     unsigned int bad = 0;
+    const bool words_ok = (umi_len & 3) == 0 && ((uintptr_t)umi & 3) == 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint8_t *u = umi + (size_t)i * umi_len;
         uint64_t key[W];
 #pragma unroll
         for (int w = 0; w < W; w++) key[w] = 0;
+        uint32_t word = 0;
         for (int b = 0; b < umi_len; b++) {
-            const uint32_t c = base_code(u[b]);
+            // (four bases per load where every UMI starts on a 4-byte boundary: twelve byte loads per
+            // read made this kernel 0.23 ms at 10^7 reads)
+            if (words_ok) {
+                if ((b & 3) == 0) word = ((const uint32_t *)u)[b >> 2];
+            } else {
+                word = (uint32_t)u[b] << (8 * (b & 3));
+            }
+            const uint32_t c = base_code((uint8_t)(word >> (8 * (b & 3))));
             bad += c > 7u ? 1u : 0u;
             const int bit = 3 * b, w = bit >> 6, sh = bit & 63;
 #pragma unroll
@@ -72,12 +81,13 @@ __global__ __launch_bounds__(256) void stage_encode_kernel(const uint8_t *__rest
                 if (q == w + 1 && sh > 61) key[q] |= (uint64_t)(c & 7u) >> (64 - sh); // a base across two words
             }
         }
-#pragma unroll
-        for (int w = 0; w < W; w++) k3[(size_t)i * W + w] = key[w];
         idx[i] = i;
-        if (composed) {
+        if (composed) { // (the UMI key is the low part of it: no array of its own)
             const uint64_t a = align_bits >= 64 ? align[i] : align[i] & ((1ull << align_bits) - 1ull);
             composed[i] = (a << (3 * umi_len)) | key[0];
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; w++) k3[(size_t)i * W + w] = key[w];
         }
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicAdd(&counters[SC_BAD], 1ull);
@@ -129,7 +139,9 @@ template <int W>
 __global__ __launch_bounds__(256) void stage_entry_heads_kernel(const uint64_t *__restrict__ flags,
                                                                 const uint64_t *__restrict__ numbers,
                                                                 const uint32_t *__restrict__ perm,
-                                                                const uint64_t *__restrict__ k3, uint32_t n,
+                                                                const uint64_t *__restrict__ k3,
+                                                                const uint64_t *__restrict__ composed, int umi_bits,
+                                                                uint32_t n,
                                                                 uint32_t *__restrict__ head_pos,
                                                                 uint32_t *__restrict__ ent_first,
                                                                 uint32_t *__restrict__ ent_bseq,
@@ -143,8 +155,12 @@ __global__ __launch_bounds__(256) void stage_entry_heads_kernel(const uint64_t *
             head_pos[e] = i;
             ent_first[e] = r;
             ent_bseq[e] = (uint32_t)(num >> 32) - 1u;
+            if (composed) { // (W == 1: the UMI key is the low part of the sorted composed key)
+                ent_key[e] = composed[i] & ((1ull << umi_bits) - 1ull);
+            } else {
 #pragma unroll
-            for (int w = 0; w < W; w++) ent_key[(size_t)e * W + w] = k3[(size_t)r * W + w];
+                for (int w = 0; w < W; w++) ent_key[(size_t)e * W + w] = k3[(size_t)r * W + w];
+            }
         }
         if (i == n - 1) {
             head_pos[(uint32_t)num] = n;
@@ -162,8 +178,16 @@ __global__ __launch_bounds__(256) void stage_fmax_kernel(const uint32_t *__restr
     uint32_t m = 0;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x)
         m = max(m, head_pos[e + 1] - head_pos[e]);
+    // one atomic per block, and a look first: one word takes ~90 accesses per microsecond
+    __shared__ uint32_t wmax[4];
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&counters[SC_FMAX], (unsigned long long)m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m && __hip_atomic_load(&counters[SC_FMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)m)
+            atomicMax(&counters[SC_FMAX], (unsigned long long)m);
+    }
 }
 
 // The maximum (or minimum) of v over the lanes of a wave that share a run of equal ids, at the
@@ -203,10 +227,13 @@ __global__ __launch_bounds__(256) void stage_reads_kernel(const uint64_t *__rest
             const unsigned long long packed =
                 ((unsigned long long)((uint32_t)score[r] ^ 0x80000000u) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
             const unsigned long long m = run_extreme<true>(valid ? packed : 0ull, s, valid, &last);
-            if (last) atomicMax(&best[s], m);
+            if (last && __hip_atomic_load(&best[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < m) atomicMax(&best[s], m);
         }
+        // (a look before the atomic: a deep position is thousands of waves' runs on one word, which takes
+        // ~90 atomics per microsecond -- and all but a few of them have nothing to lower)
         const unsigned long long mn = run_extreme<false>(valid ? (unsigned long long)r : ~0ull, b, valid, &last);
-        if (last) atomicMin(&bfirst[b], (uint32_t)mn);
+        if (last && __hip_atomic_load(&bfirst[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)mn)
+            atomicMin(&bfirst[b], (uint32_t)mn);
     }
 }
 
@@ -405,9 +432,9 @@ int stage_impl(void *workspace, const uint64_t *d_align, int align_bits, const u
     stage_heads_kernel<W><<<grid_for(n), 256, 0, s>>>(one_key ? ka : nullptr, umi_bits, d_align, align_bits, b.k3, va, n,
                                                       b.flags);
     STAGE_TRY(scan_inclusive_u64(b.flags, b.numbers, n, b.tmp, b.tmp_bytes, s));
-    stage_entry_heads_kernel<W><<<grid_for(n), 256, 0, s>>>(b.flags, b.numbers, va, b.k3, n, b.head_pos, b.ent_first,
-                                                           b.ent_bseq, b.ent_key, b.counters);
-    stage_fmax_kernel<<<grid_for(n, 256, 1024), 256, 0, s>>>(b.head_pos, n, b.counters);
+    stage_entry_heads_kernel<W><<<grid_for(n), 256, 0, s>>>(b.flags, b.numbers, va, b.k3, one_key ? ka : nullptr, umi_bits, n,
+                                                           b.head_pos, b.ent_first, b.ent_bseq, b.ent_key, b.counters);
+    stage_fmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, s>>>(b.head_pos, n, b.counters);
     // the host needs the counts to size what follows (and the verdict on the characters)
     STAGE_TRY(hipMemcpyAsync(h_pinned4, b.counters, SC_COUNT * 8, hipMemcpyDeviceToHost, s));
     STAGE_TRY(hipStreamSynchronize(s));

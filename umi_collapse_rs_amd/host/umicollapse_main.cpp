@@ -379,9 +379,14 @@ int main(int argc, char **argv)
                     break;
                 }
             }
+        // (where the reads are merged per (position, UMI): on the GPU unless something needs the host's
+        // per-read bookkeeping -- decided here because the per-read pass only encodes UMIs for the host path)
+        if (args.stage != "auto" && args.stage != "gpu" && args.stage != "host") die("--stage wants gpu, host or auto");
+        bool gpu_stage = args.stage != "host" && !args.passthrough && !args.paired && !args.track_clusters &&
+                         args.dump_staging.empty() && umi_length >= 1;
+        if (args.stage == "gpu" && !gpu_stage) die("--stage gpu does not go with --paired, --tag or --dump-staging");
         struct ReadInfo {
             uint64_t coord, ref_strand, tlen;
-            UmiKey key, nmask;
             int32_t score;
             uint8_t state; // 0 staged, 1 unmapped, 2 error, 3 second mate (not counted),
                            // 4 mate unmapped, 5 filtered (--remove-unpaired / --remove-chimeric)
@@ -389,6 +394,22 @@ int main(int argc, char **argv)
             uint32_t umi_at; // offset of the UMI in the read name
         };
         std::vector<ReadInfo> info(n_rec);
+        std::vector<UmiKey> rkey, rnm; // per read: its UMI key and N mask (host staging only: the device encodes its own)
+        auto encode_all = [&]() {       // utils/mod.rs:63-83 for every staged read; the first bad character ends the run
+            rkey.resize(n_rec);
+            rnm.resize(n_rec);
+            std::vector<uint32_t> bad(T, UINT32_MAX);
+            const uint32_t per = (n_rec + T - 1) / T;
+            umi::bgzf::parallel_for(T, T, [&](size_t t) {
+                for (uint32_t ri = (uint32_t)t * per; ri < std::min(n_rec, ((uint32_t)t + 1) * per); ri++)
+                    if (info[ri].state == 0 && !args.passthrough &&
+                        !encode_umi(in.records[ri].qname() + info[ri].umi_at, umi_length, &rkey[ri], &rnm[ri]) &&
+                        bad[t] == UINT32_MAX)
+                        bad[t] = ri;
+            });
+            for (unsigned t = 0; t < T; t++)
+                if (bad[t] != UINT32_MAX) die("Unknown character in UMI sequence");
+        };
         std::vector<std::string> errors(T);
         std::vector<uint32_t> first_error(T, UINT32_MAX);
         const uint32_t chunk = (n_rec + T - 1) / T;
@@ -413,7 +434,6 @@ int main(int argc, char **argv)
                 else if (umi_length == 0) err = "Empty UMI sequence extracted";
                 else if (umi_length > UMI_MAX_WIDE_UMI_LEN) err = "UMIs of more than 85 bases are not handled";
                 else if (at + umi_length > qn) err = "UMI runs past the end of the read name";
-                else if (!encode_umi(q + at, umi_length, &ii.key, &ii.nmask)) err = "Unknown character in UMI sequence"; // utils/mod.rs:77-79
                 if (err) {
                     ii.state = 2;
                     if (first_error[t] == UINT32_MAX) { first_error[t] = ri; errors[t] = err; }
@@ -425,6 +445,7 @@ int main(int argc, char **argv)
         });
         for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
             if (first_error[t] != UINT32_MAX) die(errors[t]);
+        if (!gpu_stage && !args.passthrough) encode_all();
 
         size_t total_read_count = 0, unmapped = 0, unpaired = 0, chimeric = 0;
         std::vector<uint32_t> out_records; // records written before dedup (--keep-unmapped, :104-106)
@@ -468,10 +489,6 @@ int main(int argc, char **argv)
             }
             t_init += now_s() - t0;
         };
-        if (args.stage != "auto" && args.stage != "gpu" && args.stage != "host") die("--stage wants gpu, host or auto");
-        bool gpu_stage = args.stage != "host" && !args.passthrough && !args.paired && !args.track_clusters &&
-                         args.dump_staging.empty() && umi_length >= 1;
-        if (args.stage == "gpu" && !gpu_stage) die("--stage gpu does not go with --paired, --tag or --dump-staging");
         if (gpu_stage) {
             std::vector<uint32_t> staged;
             staged.reserve(n_rec);
@@ -496,6 +513,7 @@ int main(int argc, char **argv)
                 }
             });
             for (uint8_t f : fits) gpu_stage = gpu_stage && f;
+            if (!gpu_stage) encode_all(); // (a coordinate beyond 32 bits: the host staging takes the file)
             if (gpu_stage) {
                 need_ctx();
                 keys.assign(ns * n_words, 0); nmask.assign(ns * n_words, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
@@ -541,12 +559,12 @@ int main(int argc, char **argv)
                     b = it->second;
                 }
                 auto &idx = sh.umi_index[b];
-                auto e = idx.find(ii.key);
+                auto e = idx.find(rkey[ri]);
                 if (args.track_clusters) entry_of[ri] = e == idx.end() ? (uint32_t)sh.entries.size() : e->second;
                 if (e == idx.end()) { // Vacant :161-163
-                    idx.emplace(ii.key, (uint32_t)sh.entries.size());
+                    idx.emplace(rkey[ri], (uint32_t)sh.entries.size());
                     sh.bucket_entries[b].push_back((uint32_t)sh.entries.size());
-                    sh.entries.push_back({ii.key, ii.nmask, 1, ii.score, ri, b});
+                    sh.entries.push_back({rkey[ri], rnm[ri], 1, ii.score, ri, b});
                 } else { // Occupied :164-175
                     Entry &en = sh.entries[e->second];
                     const bool keep_existing = merge == 0 ? true : en.score >= ii.score; // merge/mod.rs:21,35,49
