@@ -1981,7 +1981,7 @@ int umi_stage_reads_wide_device(umi_ctx *ctx, const uint64_t *d_align_key, int a
     if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
     if (align_key_bits < 1 || align_key_bits > 64) return fail(UMI_ERR_ARG, "align_key_bits must be in 1..64");
     if (merge != 0 && merge != 1) return fail(UMI_ERR_ARG, "merge must be 0 (any) or 1 (highest score, first on ties)");
-    if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
+    if (n_reads >= (1ull << 30)) return fail(UMI_ERR_ARG, "%llu reads exceed the 30-bit index space of one staging call", (unsigned long long)n_reads);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads, n_words)))) return rc;
@@ -2015,7 +2015,7 @@ int umi_stage_reads_wide(umi_ctx *ctx, const uint64_t *align_key, int align_key_
     if (n_reads && (!align_key || !umi_ascii || !keys || !freq || !rep)) return fail(UMI_ERR_ARG, "a required pointer is NULL");
     if (umi_len < 1 || umi_len > UMI_MAX_WIDE_UMI_LEN) return fail(UMI_ERR_ARG, "umi_len %d outside 1..%d", umi_len, UMI_MAX_WIDE_UMI_LEN);
     if (n_words != wide_words(umi_len)) return fail(UMI_ERR_ARG, "n_words must be %d for umi_len %d", wide_words(umi_len), umi_len);
-    if (n_reads >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "%llu reads exceed the 31-bit index space of one call", (unsigned long long)n_reads);
+    if (n_reads >= (1ull << 30)) return fail(UMI_ERR_ARG, "%llu reads exceed the 30-bit index space of one staging call", (unsigned long long)n_reads);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
     const size_t n = (size_t)n_reads, m = std::max<size_t>(n, 1), kw = 8 * (size_t)n_words;

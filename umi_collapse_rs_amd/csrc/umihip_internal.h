@@ -285,13 +285,27 @@ int stage_reads_on_device(void *workspace, const uint64_t *d_align, int align_bi
                           hipStream_t s);
 
 // ---- sort and scan primitives of the staging (umihip_radix.hip) ----
+constexpr int RADIX_BINS = 256, RADIX_MAX_PASSES = 8; // 8-bit digits; a 64-bit key has at most eight
+constexpr int RADIX_HIST_PARTS = 2048;                // blocks of a kernel that counts digits, at most
 size_t radix_sort_temp_bytes(uint32_t n);
-// stable sort of (key, value) pairs by bits [begin_bit, end_bit) of the key; the buffers are used in
-// turn, *result_in_b says where the result lies
+// stable sort of (key, value) pairs by bits [begin_bit, end_bit) of the key (n < 2^30); the buffers
+// are used in turn, *result_in_b says where the result lies.  hist_parts > 0: the digit counts were
+// taken by the kernel that wrote the keys -- block b of its hist_parts blocks put its counts of pass
+// p (bits [begin_bit + 8p, +8)) and digit d at parts[(b * passes + p) * 256 + d], zeros included,
+// parts being what radix_sort_prepare returned; that call zeroes the sort's temporaries and
+// therefore comes before that kernel
+hipError_t radix_sort_prepare(void *temp, size_t temp_bytes, uint32_t n, int begin_bit, int end_bit, uint32_t **hist_parts,
+                              hipStream_t s);
 hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
-                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s);
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s,
+                                uint32_t hist_parts = 0);
+hipError_t radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s,
+                                uint32_t hist_parts = 0);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t scan_inclusive_u64(const uint64_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes, hipStream_t s);
+// exclusive scan of a short array in place, by one block (the tile sums of a two-level scan)
+hipError_t scan_spine_u64(unsigned long long *sums, uint32_t n, hipStream_t s);
 
 // ---- directional collapse by union-find (umihip_collapse.hip) ----
 // comp[] (= label[], identity on entry) becomes the smallest index of each entry's set under the

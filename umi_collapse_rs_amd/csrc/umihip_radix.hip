@@ -28,26 +28,37 @@ namespace umihip {
 
 namespace {
 
-constexpr int RS_THREADS = 256, RS_ROUNDS = 16, RS_TILE = RS_THREADS * RS_ROUNDS, RS_RADIX = 256, RS_WAVES = RS_THREADS / 64;
-constexpr int RS_MAX_PASSES = 8;
-constexpr unsigned long long RS_HAVE = 1ull << 62, RS_PREFIX = 1ull << 63, RS_COUNT = (1ull << 62) - 1ull;
+#ifndef RS_THREADS_CFG
+#define RS_THREADS_CFG 1024
+#define RS_ROUNDS_CFG 4
+#endif
+constexpr int RS_THREADS = RS_THREADS_CFG, RS_ROUNDS = RS_ROUNDS_CFG, RS_TILE = RS_THREADS * RS_ROUNDS, RS_RADIX = 256,
+              RS_WAVES = RS_THREADS / 64;
+constexpr int RS_MAX_PASSES = RADIX_MAX_PASSES;
+static_assert(RS_RADIX == RADIX_BINS, "8-bit digits");
+// a tile's word per digit: two flag bits over a 30-bit count (n < 2^30, checked by the caller)
+constexpr uint32_t RS_HAVE = 1u << 30, RS_PREFIX = 1u << 31, RS_COUNT = (1u << 30) - 1u;
+static_assert(RS_THREADS >= RS_RADIX && RS_THREADS % 64 == 0, "a thread per digit");
 
-struct RadixPass {
-    const uint64_t *kin;
-    uint64_t *kout;
+template <typename KeyT> struct RadixPass {
+    const KeyT *kin;
+    KeyT *kout;
     const uint32_t *vin;
     uint32_t *vout;
     uint32_t n;
     int shift;
     uint32_t mask;
-    const uint32_t *digit_base;   // [256] keys of the whole input with a smaller digit
-    unsigned long long *status;   // [tiles][256], zero before the pass
-    uint32_t *ticket;             // zero before the pass
+    const uint32_t *digit_base; // [256] keys of the whole input with a smaller digit
+    uint32_t *status;           // [tiles][256], zero before the pass
+    uint32_t *ticket;           // zero before the pass
 };
 
-// digit histograms of all passes in one sweep
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int begin_bit,
-                                                         int n_passes, int end_bit, uint32_t *__restrict__ hist)
+// digit histograms of all passes in one sweep: every block writes its own counts, parts[block][pass][digit]
+// (a producer of the keys may do this itself, umihip_internal.h).  No atomics: 2,048 blocks adding
+// their 1,536 counts to one table were 3 million memory-side atomics, 0.08 ms at 10^7 keys.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const KeyT *__restrict__ keys, uint32_t n, int begin_bit,
+                                                         int n_passes, int end_bit, uint32_t *__restrict__ parts)
 {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
     for (int i = threadIdx.x; i < n_passes * RS_RADIX; i += blockDim.x) (&h[0][0])[i] = 0;
@@ -60,9 +71,28 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restr
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_passes * RS_RADIX; i += blockDim.x) {
-        const uint32_t c = (&h[0][0])[i];
-        if (c) atomicAdd(&hist[i], c);
+    uint32_t *mine = parts + (size_t)blockIdx.x * n_passes * RS_RADIX;
+    for (int i = threadIdx.x; i < n_passes * RS_RADIX; i += blockDim.x) mine[i] = (&h[0][0])[i];
+}
+
+// the parts added up: block (pass, j) takes every 16th part from j on, four at a time, and adds its
+// 256 sums to hist[pass][] (zero before).  (One block per pass walking all 2,048 parts took 86 us:
+// 512 loads in a row per thread.)
+constexpr int RS_SUM_BLOCKS = 16;
+__global__ __launch_bounds__(1024) void radix_sum_kernel(const uint32_t *__restrict__ parts, uint32_t n_parts, int n_passes,
+                                                         uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t grp[4][RS_RADIX];
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8, pass = blockIdx.x / RS_SUM_BLOCKS, j = blockIdx.x % RS_SUM_BLOCKS;
+    uint32_t c = 0;
+#pragma unroll 4
+    for (uint32_t part = j * 4 + q; part < n_parts; part += 4 * RS_SUM_BLOCKS)
+        c += parts[((size_t)part * n_passes + pass) * RS_RADIX + d];
+    grp[q][d] = c;
+    __syncthreads();
+    if (threadIdx.x < RS_RADIX) {
+        const uint32_t v = grp[0][d] + grp[1][d] + grp[2][d] + grp[3][d];
+        if (v) atomicAdd(&hist[(size_t)pass * RS_RADIX + d], v);
     }
 }
 
@@ -84,14 +114,14 @@ __global__ __launch_bounds__(RS_RADIX) void radix_base_kernel(uint32_t *__restri
     h[threadIdx.x] = off + incl - v;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
+template <typename KeyT> __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass<KeyT> a)
 {
     __shared__ uint32_t s_tile;
-    __shared__ uint32_t cnt[RS_WAVES][RS_RADIX]; // per wave: running count of every digit, then the wave's offset in the tile's run
-    __shared__ uint32_t tile_start[RS_RADIX];    // first position of digit d in the tile's digit order
-    __shared__ uint32_t gbase[RS_RADIX];         // output position of that first pair, less tile_start[d]
-    __shared__ uint32_t wtot[RS_WAVES];
-    __shared__ uint64_t skeys[RS_TILE];
+    __shared__ uint32_t cnt[RS_WAVES][RS_RADIX]; // per wave: running count of every digit; then the place of the wave's
+                                                 // first pair of the digit in the tile's digit order
+    __shared__ uint32_t gbase[RS_RADIX];         // output position of the tile's first pair of digit d, less its place in the tile
+    __shared__ uint32_t wtot[RS_RADIX / 64];
+    __shared__ KeyT skeys[RS_TILE];
     __shared__ uint32_t svals[RS_TILE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
@@ -100,8 +130,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
     const uint32_t tile = s_tile;
     const uint64_t base = (uint64_t)tile * RS_TILE;
     const uint32_t tile_n = (uint32_t)std::min<uint64_t>(RS_TILE, a.n - base);
-    // ---- rank: the wave's 1,024 pairs in 16 rounds of 64 consecutive ones
-    uint64_t key[RS_ROUNDS];
+    // ---- rank: the wave's pairs in rounds of 64 consecutive ones
+    KeyT key[RS_ROUNDS];
     uint32_t val[RS_ROUNDS], rank[RS_ROUNDS];
     volatile uint32_t *my_cnt = cnt[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -109,7 +139,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
     for (int r = 0; r < RS_ROUNDS; r++) {
         const uint32_t at = (uint32_t)wave * (RS_ROUNDS * 64) + (uint32_t)r * 64 + (uint32_t)lane;
         const bool valid = at < tile_n;
-        key[r] = valid ? a.kin[base + at] : ~0ull;
+        key[r] = valid ? a.kin[base + at] : (KeyT)~(KeyT)0;
         val[r] = valid ? a.vin[base + at] : 0u;
     }
 #pragma unroll
@@ -130,40 +160,45 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
     }
     __syncthreads();
     // ---- chain: thread d owns digit d
-    {
-        const int d = tid;
-        uint32_t c[RS_WAVES], tot = 0;
+    uint32_t tot = 0, incl = 0;
+    if (tid < RS_RADIX) {
 #pragma unroll
         for (int w = 0; w < RS_WAVES; w++) {
-            c[w] = cnt[w][d];
-            cnt[w][d] = tot; // the wave's offset inside the tile's run of digit d
-            tot += c[w];
+            const uint32_t c = cnt[w][tid];
+            cnt[w][tid] = tot; // the wave's offset inside the tile's run of digit d
+            tot += c;
         }
-        // tile_start: exclusive scan of tot over the digits
-        uint32_t incl = tot;
+        incl = tot; // exclusive scan of tot over the digits: where the tile's run of digit d starts
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(incl, o);
             if (lane >= o) incl += up;
         }
         if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < RS_RADIX) {
+        const int d = tid;
         uint32_t off = 0;
         for (int w = 0; w < wave; w++) off += wtot[w];
         const uint32_t start = off + incl - tot;
-        tile_start[d] = start;
-        unsigned long long *st = a.status + (size_t)tile * RS_RADIX + d;
-        unsigned long long before = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) cnt[w][d] += start;
+        uint32_t *st = a.status + (size_t)tile * RS_RADIX + d;
+        uint32_t before = 0;
         if (tile == 0) {
-            __hip_atomic_store(st, RS_HAVE | RS_PREFIX | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st, RS_HAVE | RS_PREFIX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(st, RS_HAVE | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st, RS_HAVE | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (tile t drew its ticket before this one: it is running.)  Eight tiles' words are asked for
             // at once: a trip to the memory side per tile would make the tiles that start together wait
             // for one another in a row
-            constexpr int LB = 8;
+#ifndef RS_LB_CFG
+#define RS_LB_CFG 8
+#endif
+            constexpr int LB = RS_LB_CFG;
             bool done = false;
             for (int64_t t = (int64_t)tile - 1; t >= 0 && !done; t -= LB) {
-                unsigned long long v[LB];
+                uint32_t v[LB];
 #pragma unroll
                 for (int q = 0; q < LB; q++)
                     v[q] = t - q >= 0 ? __hip_atomic_load(a.status + (size_t)(t - q) * RS_RADIX + d, __ATOMIC_RELAXED,
@@ -171,17 +206,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
                                       : (RS_HAVE | RS_PREFIX);
 #pragma unroll
                 for (int q = 0; q < LB; q++) {
-                    if (done) break;
-                    while (!(v[q] & RS_HAVE))
-                        v[q] = __hip_atomic_load(a.status + (size_t)(t - q) * RS_RADIX + d, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                    before += v[q] & RS_COUNT;
-                    done = (v[q] & RS_PREFIX) != 0;
+                    if (!done) {
+                        while (!(v[q] & RS_HAVE))
+                            v[q] = __hip_atomic_load(a.status + (size_t)(t - q) * RS_RADIX + d, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                        before += v[q] & RS_COUNT;
+                        done = (v[q] & RS_PREFIX) != 0;
+                    }
                 }
             }
             __hip_atomic_store(st, RS_HAVE | RS_PREFIX | (before + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        gbase[d] = a.digit_base[d] + (uint32_t)before - start;
+        gbase[d] = a.digit_base[d] + before - start;
     }
     __syncthreads();
     // ---- move: to LDS in digit order, then out in runs
@@ -190,14 +226,14 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(RadixPass a)
         const uint32_t at = (uint32_t)wave * (RS_ROUNDS * 64) + (uint32_t)r * 64 + (uint32_t)lane;
         if (at < tile_n) {
             const uint32_t d = (uint32_t)(key[r] >> a.shift) & a.mask;
-            const uint32_t pos = tile_start[d] + cnt[wave][d] + rank[r];
+            const uint32_t pos = cnt[wave][d] + rank[r];
             skeys[pos] = key[r];
             svals[pos] = val[r];
         }
     }
     __syncthreads();
     for (uint32_t i = tid; i < tile_n; i += RS_THREADS) {
-        const uint64_t k = skeys[i];
+        const KeyT k = skeys[i];
         const uint32_t d = (uint32_t)(k >> a.shift) & a.mask;
         const uint32_t pos = gbase[d] + i;
         a.kout[pos] = k;
@@ -284,9 +320,10 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint64_t *
 inline uint32_t tiles_of(uint32_t n, uint32_t tile) { return std::max(1u, (uint32_t)(((uint64_t)n + tile - 1) / tile)); }
 
 struct RadixTemp {
-    uint32_t *hist;             // [RS_MAX_PASSES][256]
-    uint32_t *tickets;          // [RS_MAX_PASSES + 1]
-    unsigned long long *status; // [passes][tiles][256]
+    uint32_t *hist;    // [RS_MAX_PASSES][256]
+    uint32_t *tickets; // [RS_MAX_PASSES + 1]
+    uint32_t *status;  // [passes][tiles][256]
+    uint32_t *parts;   // [RADIX_HIST_PARTS][passes][256]: written whole by whoever counts, not zeroed
     size_t zero_bytes, total;
 };
 RadixTemp radix_carve(void *temp, uint32_t n, int passes)
@@ -298,34 +335,39 @@ RadixTemp radix_carve(void *temp, uint32_t n, int passes)
     off += (size_t)RS_MAX_PASSES * RS_RADIX * 4;
     t.tickets = (uint32_t *)(p + off);
     off += 64;
-    t.status = (unsigned long long *)(p + off);
-    off += (size_t)passes * tiles_of(n, RS_TILE) * RS_RADIX * 8;
-    t.zero_bytes = t.total = (off + 255) & ~(size_t)255;
+    t.status = (uint32_t *)(p + off);
+    off += (size_t)passes * tiles_of(n, RS_TILE) * RS_RADIX * 4;
+    t.zero_bytes = off = (off + 255) & ~(size_t)255;
+    t.parts = (uint32_t *)(p + off);
+    off += (size_t)RADIX_HIST_PARTS * RS_MAX_PASSES * RS_RADIX * 4;
+    t.total = off;
     return t;
 }
 
-} // namespace
-
-size_t radix_sort_temp_bytes(uint32_t n) { return radix_carve(nullptr, n, RS_MAX_PASSES).total; }
-
-hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
-                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s)
+template <typename KeyT>
+hipError_t radix_sort_impl(KeyT *keys_a, KeyT *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n, int begin_bit,
+                           int end_bit, void *temp, size_t temp_bytes, uint32_t hist_parts, bool *result_in_b, hipStream_t s)
 {
     *result_in_b = false;
     if (n == 0 || end_bit <= begin_bit) return hipSuccess;
-    if (begin_bit < 0 || end_bit > 64) return hipErrorInvalidValue;
+    if (begin_bit < 0 || end_bit > (int)sizeof(KeyT) * 8 || n > RS_COUNT) return hipErrorInvalidValue;
     const int passes = (end_bit - begin_bit + 7) / 8;
     const RadixTemp t = radix_carve(temp, n, passes);
     if (t.total > temp_bytes) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(temp, 0, t.zero_bytes, s);
-    if (e != hipSuccess) return e;
     const uint32_t tiles = tiles_of(n, RS_TILE);
-    radix_hist_kernel<<<std::min(tiles_of(n, 256 * 16), 2048u), 256, 0, s>>>(keys_a, n, begin_bit, passes, end_bit, t.hist);
+    if (hist_parts > (uint32_t)RADIX_HIST_PARTS) return hipErrorInvalidValue;
+    if (!hist_parts) {
+        const hipError_t e = hipMemsetAsync(temp, 0, t.zero_bytes, s);
+        if (e != hipSuccess) return e;
+        hist_parts = std::min(tiles_of(n, 256 * 16), (uint32_t)RADIX_HIST_PARTS);
+        radix_hist_kernel<KeyT><<<hist_parts, 256, 0, s>>>(keys_a, n, begin_bit, passes, end_bit, t.parts);
+    }
+    radix_sum_kernel<<<passes * RS_SUM_BLOCKS, 1024, 0, s>>>(t.parts, hist_parts, passes, t.hist);
     radix_base_kernel<<<passes, RS_RADIX, 0, s>>>(t.hist);
-    uint64_t *kin = keys_a, *kout = keys_b;
+    KeyT *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
     for (int p = 0; p < passes; p++) {
-        RadixPass a;
+        RadixPass<KeyT> a;
         a.kin = kin;
         a.kout = kout;
         a.vin = vin;
@@ -336,7 +378,7 @@ hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
         a.digit_base = t.hist + (size_t)p * RS_RADIX;
         a.status = t.status + (size_t)p * tiles * RS_RADIX;
         a.ticket = t.tickets + p;
-        radix_onesweep_kernel<<<tiles, RS_THREADS, 0, s>>>(a);
+        radix_onesweep_kernel<KeyT><<<tiles, RS_THREADS, 0, s>>>(a);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
@@ -344,7 +386,46 @@ hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
     return hipGetLastError();
 }
 
+} // namespace
+
+size_t radix_sort_temp_bytes(uint32_t n) { return radix_carve(nullptr, n, RS_MAX_PASSES).total; }
+
+// The digit counts may come from the kernel that produces the keys: radix_sort_prepare zeroes the
+// temporaries and returns where that kernel's blocks put their counts (umihip_internal.h).
+hipError_t radix_sort_prepare(void *temp, size_t temp_bytes, uint32_t n, int begin_bit, int end_bit, uint32_t **hist_parts,
+                              hipStream_t s)
+{
+    *hist_parts = nullptr;
+    if (n == 0 || end_bit <= begin_bit) return hipSuccess;
+    const RadixTemp t = radix_carve(temp, n, (end_bit - begin_bit + 7) / 8);
+    if (t.total > temp_bytes) return hipErrorInvalidValue;
+    *hist_parts = t.parts;
+    return hipMemsetAsync(temp, 0, t.zero_bytes, s);
+}
+
+hipError_t radix_sort_pairs_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s,
+                                uint32_t hist_parts)
+{
+    return radix_sort_impl<uint64_t>(keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, temp, temp_bytes, hist_parts,
+                                     result_in_b, s);
+}
+hipError_t radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                                int begin_bit, int end_bit, void *temp, size_t temp_bytes, bool *result_in_b, hipStream_t s,
+                                uint32_t hist_parts)
+{
+    return radix_sort_impl<uint32_t>(keys_a, keys_b, vals_a, vals_b, n, begin_bit, end_bit, temp, temp_bytes, hist_parts,
+                                     result_in_b, s);
+}
+
 size_t scan_temp_bytes(uint32_t n) { return ((size_t)tiles_of(n, SC_TILE) * 8 + 255) & ~(size_t)255; }
+
+hipError_t scan_spine_u64(unsigned long long *sums, uint32_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    scan_spine_kernel<<<1, 1024, 0, s>>>(sums, n);
+    return hipGetLastError();
+}
 
 hipError_t scan_inclusive_u64(const uint64_t *in, uint64_t *out, uint32_t n, void *temp, size_t temp_bytes, hipStream_t s)
 {
