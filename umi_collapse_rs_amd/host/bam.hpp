@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include "bgzf.hpp"
+
 namespace umi {
 namespace bam {
 
@@ -99,7 +101,15 @@ struct Record {
         volatile float sum = 0.0f;
         const uint8_t *q = qual();
         const int32_t n = l_seq();
-        for (int32_t i = 0; i < n; i++) sum = sum + (float)q[i];
+        if (n < 65536) {
+            // every partial sum is an integer below 2^24, which f32 holds exactly: the running f32
+            // sum of the reference equals the integer sum (and this loop vectorises)
+            uint32_t isum = 0;
+            for (int32_t i = 0; i < n; i++) isum += q[i];
+            sum = (float)isum;
+        } else {
+            for (int32_t i = 0; i < n; i++) sum = sum + (float)q[i];
+        }
         volatile float avg = sum / (float)n;
         float v = avg;
         if (v != v) return 0;
@@ -110,7 +120,7 @@ struct Record {
 };
 
 struct File {
-    std::vector<uint8_t> data; // whole decompressed stream
+    umi::bgzf::Bytes data;     // whole decompressed stream
     size_t header_len = 0;     // magic .. end of the reference list: copied verbatim to the output
                                // (Header::from_template, deduplicate_sam.rs:357-362)
     int32_t n_ref = 0;

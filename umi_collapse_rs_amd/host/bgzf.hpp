@@ -7,12 +7,19 @@
 
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -25,21 +32,37 @@ struct IoError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-inline std::vector<uint8_t> read_file(const std::string &path)
-{
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw IoError("Invalid input path: " + path); // deduplicate_sam.rs:78
-    std::fseek(f, 0, SEEK_END);
-    long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> buf((size_t)sz);
-    if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) {
-        std::fclose(f);
-        throw IoError("short read on " + path);
+// Bytes whose storage is not zeroed when it is sized: a file of 2 M reads is 0.4 GB inflated, and
+// std::vector<uint8_t>(n) would write all of it once, on one thread, before the inflate threads
+// write it again (0.08 s of a run of 0.4 s).
+// Large blocks are 2 MB-aligned and marked for transparent huge pages: first touch and the unmapping
+// at exit are per page, and 0.4 GB is 100,000 small ones.
+template <class T> struct default_init_allocator {
+    using value_type = T;
+    default_init_allocator() = default;
+    template <class U> default_init_allocator(const default_init_allocator<U> &) noexcept {}
+    template <class U> struct rebind {
+        using other = default_init_allocator<U>;
+    };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T), huge = 2u << 20;
+        void *p = nullptr;
+        if (bytes >= 2 * huge) {
+            if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0) throw std::bad_alloc();
+            (void)madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+        } else if (!(p = std::malloc(bytes ? bytes : 1))) {
+            throw std::bad_alloc();
+        }
+        return (T *)p;
     }
-    std::fclose(f);
-    return buf;
-}
+    void deallocate(T *p, size_t) noexcept { std::free(p); }
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const default_init_allocator<U> &) const noexcept { return true; }
+    template <class U> bool operator!=(const default_init_allocator<U> &) const noexcept { return false; }
+};
+using Bytes = std::vector<uint8_t, default_init_allocator<uint8_t>>;
 
 struct BlockRef {
     size_t in_off;   // start of the deflate payload
@@ -47,6 +70,38 @@ struct BlockRef {
     uint32_t out_len;
     size_t out_off;
 };
+
+inline void parallel_for(size_t n, unsigned threads, const std::function<void(size_t)> &fn);
+
+// the whole file, read by `threads` readers at once (pread on slices)
+inline Bytes read_file(const std::string &path, unsigned threads = 1)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw IoError("Invalid input path: " + path); // deduplicate_sam.rs:78
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        ::close(fd);
+        throw IoError("Invalid input path: " + path);
+    }
+    const size_t sz = (size_t)st.st_size, slice = 8u << 20;
+    Bytes buf(sz);
+    try {
+        parallel_for((sz + slice - 1) / slice, threads, [&](size_t i) {
+            size_t off = i * slice;
+            const size_t end = std::min(sz, off + slice);
+            while (off < end) {
+                const ssize_t got = ::pread(fd, buf.data() + off, end - off, (off_t)off);
+                if (got <= 0) throw IoError("short read on " + path);
+                off += (size_t)got;
+            }
+        });
+    } catch (...) {
+        ::close(fd);
+        throw;
+    }
+    ::close(fd);
+    return buf;
+}
 
 inline void parallel_for(size_t n, unsigned threads, const std::function<void(size_t)> &fn)
 {
@@ -72,7 +127,7 @@ inline void parallel_for(size_t n, unsigned threads, const std::function<void(si
 
 // Whole-file BGZF decompression: scan the block headers (BSIZE in the BC subfield),
 // read ISIZE from each trailer, inflate all blocks in parallel into one buffer.
-inline std::vector<uint8_t> decompress(const std::vector<uint8_t> &in, unsigned threads)
+inline Bytes decompress(const Bytes &in, unsigned threads)
 {
     std::vector<BlockRef> blocks;
     size_t off = 0, total = 0;
@@ -102,67 +157,139 @@ inline std::vector<uint8_t> decompress(const std::vector<uint8_t> &in, unsigned 
         total += isize;
         off += bsize;
     }
-    std::vector<uint8_t> out(total);
-    parallel_for(blocks.size(), threads, [&](size_t i) {
-        const BlockRef &b = blocks[i];
-        if (b.out_len == 0) return;
+    Bytes out(total); // (not zeroed: the inflate threads are the first to touch it)
+    // a run of blocks per task, one inflate state per run
+    const size_t run = 16, n_runs = (blocks.size() + run - 1) / run;
+    parallel_for(n_runs, threads, [&](size_t r) {
         z_stream zs;
         std::memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, -15) != Z_OK) throw IoError("inflateInit2 failed");
-        zs.next_in = const_cast<Bytef *>(in.data() + b.in_off);
-        zs.avail_in = b.in_len;
-        zs.next_out = out.data() + b.out_off;
-        zs.avail_out = b.out_len;
-        const int rc = inflate(&zs, Z_FINISH);
+        for (size_t i = r * run; i < std::min(blocks.size(), (r + 1) * run); i++) {
+            const BlockRef &b = blocks[i];
+            if (b.out_len == 0) continue;
+            if (i != r * run) inflateReset2(&zs, -15);
+            zs.next_in = const_cast<Bytef *>(in.data() + b.in_off);
+            zs.avail_in = b.in_len;
+            zs.next_out = out.data() + b.out_off;
+            zs.avail_out = b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) {
+                inflateEnd(&zs);
+                throw IoError("Failed to parse record: corrupt BGZF block");
+            }
+        }
         inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) throw IoError("Failed to parse record: corrupt BGZF block");
     });
     return out;
 }
 
-// BGZF compression of a whole buffer: 0xff00-byte payloads, parallel deflate, EOF block.
-inline void compress_to_file(const std::string &path, const uint8_t *data, size_t len, unsigned threads, int level = 6)
+// BGZF compression of a stream given as pieces (the header, runs of surviving records: nothing is
+// copied together first): 0xff00-byte payloads, parallel deflate -- a run of blocks per task, one
+// deflate state per run, a block's payload gathered into a buffer that stays in the core's cache --
+// while one thread writes the finished runs to the file in order; EOF block.
+struct Piece {
+    const uint8_t *p;
+    size_t len;
+};
+inline void compress_pieces_to_file(const std::string &path, const std::vector<Piece> &pieces, unsigned threads, int level = 6)
 {
-    constexpr size_t PAYLOAD = 0xff00;
-    const size_t nblk = (len + PAYLOAD - 1) / PAYLOAD;
-    std::vector<std::vector<uint8_t>> out(nblk);
-    parallel_for(nblk, threads, [&](size_t i) {
-        const size_t o = i * PAYLOAD, n = std::min(PAYLOAD, len - o);
-        std::vector<uint8_t> &b = out[i];
-        b.resize(18 + compressBound((uLong)n) + 8);
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw IoError("deflateInit2 failed");
-        zs.next_in = const_cast<Bytef *>(data + o);
-        zs.avail_in = (uInt)n;
-        zs.next_out = b.data() + 18;
-        zs.avail_out = (uInt)(b.size() - 18 - 8);
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END) throw IoError("deflate failed");
-        const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
-        if (bsize > 0xffff) throw IoError("BGZF block overflow");
-        const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
-                                 (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
-        std::memcpy(b.data(), hdr, 18);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + o, (uInt)n);
-        uint8_t *t = b.data() + 18 + clen;
-        for (int k = 0; k < 4; k++) t[k] = (uint8_t)(crc >> (8 * k));
-        for (int k = 0; k < 4; k++) t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k));
-        b.resize(18 + clen + 8);
-    });
-    FILE *f = std::fopen(path.c_str(), "wb");
-    if (!f) throw IoError("cannot open output " + path);
-    for (auto &b : out)
-        if (std::fwrite(b.data(), 1, b.size(), f) != b.size()) {
-            std::fclose(f);
-            throw IoError("Failed to write the record");
+    constexpr size_t PAYLOAD = 0xff00, RUN = 16, SLOT = 18 + 0x10000 + 1024 + 8;
+    std::vector<size_t> start(pieces.size() + 1, 0); // offset of every piece in the stream
+    for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].len;
+    const size_t len = start.back(), nblk = (len + PAYLOAD - 1) / PAYLOAD, n_runs = (nblk + RUN - 1) / RUN;
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw IoError("cannot open output " + path);
+    // (compressBound of a 0xff00 payload is below 0x10000 + 1024; address space only: pages are touched as written)
+    Bytes slot_bytes(std::max<size_t>(nblk, 1) * SLOT);
+    uint8_t *const slots = slot_bytes.data();
+    std::vector<uint32_t> size_of(nblk, 0);
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[n_runs + 1]);
+    for (size_t r = 0; r <= n_runs; r++) done[r].store(0);
+    std::atomic<bool> write_failed{false};
+    auto write_all = [&](const uint8_t *p, size_t n) {
+        while (n) {
+            const ssize_t w = ::write(fd, p, n);
+            if (w <= 0) {
+                write_failed = true;
+                return;
+            }
+            p += w;
+            n -= (size_t)w;
         }
+    };
+    std::thread writer([&] {
+        for (size_t r = 0; r < n_runs && !write_failed; r++) {
+            while (done[r].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+            if (done[r].load() < 0) return; // (a compressor failed)
+            for (size_t i = r * RUN; i < std::min(nblk, (r + 1) * RUN); i++) write_all(slots + i * SLOT, size_of[i]);
+        }
+    });
+    std::string err;
+    try {
+        parallel_for(n_runs, threads, [&](size_t r) {
+            struct Flag { // (the writer is never left waiting for a run that will not come)
+                std::atomic<int> &f;
+                int v = -1;
+                ~Flag() { f.store(v, std::memory_order_release); }
+            } flag{done[r]};
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw IoError("deflateInit2 failed");
+            std::unique_ptr<uint8_t[]> payload(new uint8_t[PAYLOAD]);
+            size_t piece = std::upper_bound(start.begin(), start.end(), r * RUN * PAYLOAD) - start.begin() - 1;
+            for (size_t i = r * RUN; i < std::min(nblk, (r + 1) * RUN); i++) {
+                const size_t o = i * PAYLOAD, n = std::min(PAYLOAD, len - o);
+                for (size_t got = 0; got < n;) { // the block's bytes out of the pieces
+                    while (start[piece + 1] <= o + got) piece++;
+                    const size_t at = o + got - start[piece], take = std::min(n - got, pieces[piece].len - at);
+                    std::memcpy(payload.get() + got, pieces[piece].p + at, take);
+                    got += take;
+                }
+                uint8_t *b = slots + i * SLOT;
+                if (i != r * RUN) deflateReset(&zs);
+                zs.next_in = payload.get();
+                zs.avail_in = (uInt)n;
+                zs.next_out = b + 18;
+                zs.avail_out = (uInt)(SLOT - 18 - 8);
+                const int rc = deflate(&zs, Z_FINISH);
+                const size_t clen = zs.total_out;
+                if (rc != Z_STREAM_END) {
+                    deflateEnd(&zs);
+                    throw IoError("deflate failed");
+                }
+                const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+                if (bsize > 0xffff) {
+                    deflateEnd(&zs);
+                    throw IoError("BGZF block overflow");
+                }
+                const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                         (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+                std::memcpy(b, hdr, 18);
+                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), payload.get(), (uInt)n);
+                uint8_t *t = b + 18 + clen;
+                for (int k = 0; k < 4; k++) t[k] = (uint8_t)(crc >> (8 * k));
+                for (int k = 0; k < 4; k++) t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k));
+                size_of[i] = (uint32_t)(18 + clen + 8);
+            }
+            deflateEnd(&zs);
+            flag.v = 1;
+        });
+    } catch (const std::exception &e) {
+        err = e.what();
+    }
+    writer.join();
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0,
                                     0, 0, 0, 0, 0, 0, 0, 0};
-    std::fwrite(eof, 1, sizeof(eof), f);
-    std::fclose(f);
+    if (err.empty() && !write_failed) write_all(eof, sizeof(eof));
+    ::close(fd);
+    if (!err.empty()) throw IoError(err);
+    if (write_failed) throw IoError("Failed to write the record");
+}
+
+// BGZF compression of a whole buffer
+inline void compress_to_file(const std::string &path, const uint8_t *data, size_t len, unsigned threads, int level = 6)
+{
+    compress_pieces_to_file(path, std::vector<Piece>{{data, len}}, threads, level);
 }
 
 } // namespace bgzf

@@ -291,6 +291,7 @@ double now_s()
 
 int main(int argc, char **argv)
 {
+    const double t_main_realtime = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     Cli args = parse(argc, argv);
     const double t_start = now_s();
     if (args.merge.empty()) args.merge = args.mode == "fastq" ? "avgqual" : "mapqual"; // main.rs:33-39
@@ -338,11 +339,36 @@ int main(int argc, char **argv)
             return c;
         });
 
+    // finer split of the program's time, printed with UMICOLLAPSE_CLOCK (tools/e2e_probe.py)
+    std::vector<std::pair<const char *, double>> laps;
+    double t_lap = now_s();
+    auto lap = [&](const char *what) {
+        const double t = now_s();
+        laps.emplace_back(what, t - t_lap);
+        t_lap = t;
+    };
+    auto leave = [&]() {
+        if (warm.valid()) warm.wait(); // (a file without staged reads: the start-up thread may still be at it)
+        if (std::getenv("UMICOLLAPSE_CLOCK")) { // (for tools/e2e_probe.py: what lies before main and after _Exit)
+            std::fprintf(stderr, "laps:");
+            for (const auto &l : laps) std::fprintf(stderr, " %s %.3f", l.first, l.second);
+            std::fprintf(stderr, "\nclock: main at %.6f, exit at %.6f (realtime)\n", t_main_realtime,
+                         std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+        }
+        std::fflush(nullptr);
+        std::_Exit(0); // the output file is closed; device memory and the runtime go with the process
+    };
     try {
         // ---- read: BGZF inflate (threaded) + BAM parse
         umi::bam::File in;
-        in.data = umi::bgzf::decompress(umi::bgzf::read_file(args.input), args.num_threads);
+        // (the compressed bytes are not given back before the process ends: unmapping 0.1 GB takes 6 ms)
+        static umi::bgzf::Bytes raw;
+        raw = umi::bgzf::read_file(args.input, args.num_threads);
+        lap("read");
+        in.data = umi::bgzf::decompress(raw, args.num_threads);
+        lap("inflate");
         in.parse();
+        lap("parse");
         const double t_read = now_s();
 
         // ---- staging: deduplicate_sam.rs:93-177, in three passes so that --num-threads helps:
@@ -410,6 +436,19 @@ int main(int argc, char **argv)
             for (unsigned t = 0; t < T; t++)
                 if (bad[t] != UINT32_MAX) die("Unknown character in UMI sequence");
         };
+        // GPU staging: what the device wants of a read -- alignment key, UMI text, score -- is written by the
+        // per-read pass itself, at the read's own index (closed up afterwards if some reads are not staged)
+        using U64s = std::vector<uint64_t, umi::bgzf::default_init_allocator<uint64_t>>;
+        using I32s = std::vector<int32_t, umi::bgzf::default_init_allocator<int32_t>>;
+        U64s akey, rep64;
+        umi::bgzf::Bytes umis;
+        I32s sc;
+        std::vector<uint8_t> fits(T, 1);
+        if (gpu_stage) {
+            akey.resize(n_rec);
+            umis.resize((size_t)n_rec * umi_length);
+            sc.resize(n_rec);
+        }
         std::vector<std::string> errors(T);
         std::vector<uint32_t> first_error(T, UINT32_MAX);
         const uint32_t chunk = (n_rec + T - 1) / T;
@@ -441,10 +480,19 @@ int main(int argc, char **argv)
                 }
                 ii.score = merge == 2 ? (int32_t)r.mapq() : r.avg_qual();
                 ii.umi_at = (uint32_t)at;
+                if (gpu_stage) {
+                    // Alignment{strand, coord, ref} in 64 bits: ref id (31) | strand (1) | coordinate (32)
+                    const int64_t c = (int64_t)ii.coord;
+                    if (c < INT32_MIN || c > INT32_MAX) fits[t] = 0;
+                    akey[ri] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c;
+                    std::memcpy(&umis[(size_t)ri * umi_length], q + at, umi_length);
+                    sc[ri] = ii.score;
+                }
             }
         });
         for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
             if (first_error[t] != UINT32_MAX) die(errors[t]);
+        lap("per-read");
         if (!gpu_stage && !args.passthrough) encode_all();
 
         size_t total_read_count = 0, unmapped = 0, unpaired = 0, chimeric = 0;
@@ -469,8 +517,9 @@ int main(int argc, char **argv)
         size_t n = 0, nb = 0, max_umi = 0;
         bool any_n = false;
         const int n_words = umi_length ? (int)((3 * umi_length + 63) / 64) : 1; // words per key (bitset.rs:17-18)
-        std::vector<uint64_t> keys, nmask, off; // keys / nmask: n_words words per entry
-        std::vector<int32_t> freq;
+        // (not zeroed when sized: the staging call writes them)
+        std::vector<uint64_t, umi::bgzf::default_init_allocator<uint64_t>> keys, nmask, off; // keys / nmask: n_words words per entry
+        std::vector<int32_t, umi::bgzf::default_init_allocator<int32_t>> freq;
         std::vector<uint32_t> rep;
         std::vector<std::vector<uint32_t>> global_of;
         std::vector<uint32_t> entry_of;
@@ -490,44 +539,48 @@ int main(int argc, char **argv)
             t_init += now_s() - t0;
         };
         if (gpu_stage) {
-            std::vector<uint32_t> staged;
-            staged.reserve(n_rec);
-            for (uint32_t ri = 0; ri < n_rec; ri++)
-                if (info[ri].state == 0) staged.push_back(ri);
-            const size_t ns = staged.size();
-            std::vector<uint64_t> akey(ns), rep64(ns);
-            std::vector<uint8_t> umis(ns * umi_length);
-            std::vector<int32_t> sc(ns);
-            std::vector<uint8_t> fits(T, 1);
-            const size_t per = (ns + T - 1) / T;
-            umi::bgzf::parallel_for(T, T, [&](size_t t) {
-                for (size_t j = t * per; j < std::min(ns, (t + 1) * per); j++) {
-                    const uint32_t ri = staged[j];
-                    const ReadInfo &ii = info[ri];
-                    // Alignment{strand, coord, ref} in 64 bits: ref id (31) | strand (1) | coordinate (32)
-                    const int64_t c = (int64_t)ii.coord;
-                    if (c < INT32_MIN || c > INT32_MAX) fits[t] = 0;
-                    akey[j] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c;
-                    std::memcpy(&umis[j * umi_length], in.records[ri].qname() + ii.umi_at, umi_length);
-                    sc[j] = ii.score;
+            // the staged reads closed up (nothing moves while every read so far is staged)
+            std::vector<uint32_t> staged; // staged[j] = record of the j-th staged read, once a read has been left out
+            bool moved = false;
+            size_t ns = 0;
+            for (uint32_t ri = 0; ri < n_rec; ri++) {
+                if (info[ri].state != 0) {
+                    if (!moved) {
+                        moved = true;
+                        staged.reserve(n_rec);
+                        for (uint32_t j = 0; j < ri; j++) staged.push_back(j);
+                    }
+                    continue;
                 }
-            });
+                if (moved) {
+                    akey[ns] = akey[ri];
+                    std::memmove(&umis[ns * umi_length], &umis[(size_t)ri * umi_length], umi_length);
+                    sc[ns] = sc[ri];
+                    staged.push_back(ri);
+                }
+                ns++;
+            }
+            rep64.resize(ns);
             for (uint8_t f : fits) gpu_stage = gpu_stage && f;
+            lap("fill");
             if (!gpu_stage) encode_all(); // (a coordinate beyond 32 bits: the host staging takes the file)
             if (gpu_stage) {
                 need_ctx();
-                keys.assign(ns * n_words, 0); nmask.assign(ns * n_words, 0); freq.assign(ns, 0); off.assign(ns + 1, 0);
+                lap("wait-gpu");
+                keys.resize(ns * n_words); nmask.resize(ns * n_words); freq.resize(ns); off.resize(ns + 1);
                 uint64_t ne = 0, nbk = 0;
                 if (lib.stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, n_words, merge != 0 ? 1 : 0,
                                     keys.data(), nmask.data(), freq.data(), rep64.data(), off.data(), &ne, &nbk) != UMI_OK)
                     die(lib.last_error());
+                lap("stage-call");
                 n = (size_t)ne;
                 nb = (size_t)nbk;
                 keys.resize(n * n_words); nmask.resize(n * n_words); freq.resize(n); off.resize(nb + 1);
                 rep.resize(n);
-                for (size_t i = 0; i < n; i++) rep[i] = staged[rep64[i]];
+                for (size_t i = 0; i < n; i++) rep[i] = moved ? staged[rep64[i]] : (uint32_t)rep64[i];
                 for (uint64_t m : nmask) any_n |= m != 0;
                 for (size_t b = 0; b < nb; b++) max_umi = std::max<size_t>(max_umi, off[b + 1] - off[b]);
+                lap("after-stage");
             }
         }
         if (!gpu_stage) {
@@ -625,6 +678,7 @@ int main(int argc, char **argv)
         }
 
         // ---- the hot path: one batched call replaces the bucket loop :207-233
+        lap("to-hot-path");
         std::vector<uint8_t> kept(n + 1, 0);
         std::vector<uint32_t> root(args.track_clusters ? n + 1 : 0);
         umi_stats st;
@@ -709,10 +763,25 @@ int main(int argc, char **argv)
 
         // ---- write: header verbatim (Header::from_template :357-362) + surviving records verbatim
         constexpr size_t TAG_BYTES = 3 * 7; // three int32 aux fields
+        lap("hot-path+select");
+        if (tagged.empty()) {
+            // the stream as pieces of the input (neighbouring survivors are one piece): the compressor
+            // gathers each block's 64 KB itself, nothing is copied together first
+            std::vector<umi::bgzf::Piece> pieces;
+            pieces.reserve(out_records.size() / 2 + 2);
+            pieces.push_back({in.data.data(), in.header_len});
+            for (uint32_t ri : out_records) {
+                const uint8_t *rb = in.records[ri].begin;
+                const size_t len = (size_t)(in.records[ri].end - rb);
+                if (pieces.back().p + pieces.back().len == rb) pieces.back().len += len;
+                else pieces.push_back({rb, len});
+            }
+            umi::bgzf::compress_pieces_to_file(args.output, pieces, args.num_threads, args.compress_level);
+        } else {
         size_t out_len = in.header_len;
         for (uint32_t ri : out_records) out_len += (size_t)(in.records[ri].end - in.records[ri].begin);
         for (uint32_t ri : tagged) out_len += (size_t)(in.records[ri].end - in.records[ri].begin) + TAG_BYTES;
-        std::vector<uint8_t> out(out_len);
+        umi::bgzf::Bytes out(out_len);
         std::memcpy(out.data(), in.data.data(), in.header_len);
         size_t o = in.header_len;
         for (uint32_t ri : out_records) {
@@ -740,6 +809,8 @@ int main(int argc, char **argv)
             }
         }
         umi::bgzf::compress_to_file(args.output, out.data(), out.size(), args.num_threads, args.compress_level);
+        }
+        lap("write");
         const double t_end = now_s();
 
         // counters of deduplicate_sam.rs:243-268
@@ -760,10 +831,9 @@ int main(int argc, char **argv)
                      t_read - t_start, gpu_stage ? "gpu" : "host", t_stage0 - t_read - (gpu_stage ? t_init : 0.0), t_init,
                      t_gpu1 - t_gpu0, (unsigned long long)st.n_pairs, t_end - t_gpu1);
         std::fprintf(stderr, "UMI collapsing finished in %.3f seconds\n", t_end - t_start); // main.rs:97-102
+        leave(); // (from inside the scope of the file's buffers: they go with the process, unmapped by nobody)
     } catch (const std::exception &e) {
         die(e.what());
     }
-    if (warm.valid()) warm.wait(); // (a file without staged reads: the start-up thread may still be at it)
-    std::fflush(nullptr);
-    std::_Exit(0); // the output file is closed; device memory and the runtime go with the process
+    leave();
 }
