@@ -132,37 +132,53 @@ struct File {
     // outside the buffer.
     void parse()
     {
+        parse_behind([](size_t) {});
+    }
+    // need(upto): called before any byte below `upto` is looked at (the inflate may still be running
+    // ahead of the parse: umi::bgzf::Inflater::wait)
+    template <class Need> void parse_behind(Need need)
+    {
         const uint8_t *p = data.data();
         const size_t size = data.size();
+        need(12);
         if (size < 12 || std::memcmp(p, "BAM\1", 4) != 0) throw FormatError("Invalid input path: not a BAM file");
         const int32_t l_text = rd_i32(p + 4);
         if (l_text < 0 || (size_t)l_text > size - 12) throw FormatError("truncated BAM header");
         size_t q = 8 + (size_t)l_text; // offsets, not pointers: nothing is formed past the buffer
+        need(q + 4);
         n_ref = rd_i32(p + q);
         q += 4;
         if (n_ref < 0 || (size_t)n_ref > (size - q) / 8) throw FormatError("truncated BAM header");
         for (int32_t r = 0; r < n_ref; r++) {
             if (size - q < 4) throw FormatError("truncated BAM header");
+            need(q + 4);
             const int32_t l_name = rd_i32(p + q);
             q += 4;
             if (l_name < 0 || size - q < 4 || (size_t)l_name > size - q - 4) throw FormatError("truncated BAM header");
             q += (size_t)l_name + 4;
         }
         header_len = q;
+        records.reserve(size / 96); // (a guess; it grows if the records are shorter)
+        size_t have = 0; // bytes known to be there
         while (q < size) {
             if (size - q < 4) throw FormatError("Failed to parse record");
+            if (q + 36 > have) { // (a stretch at a time: need() may have to look at the inflate's flags)
+                have = std::min(size, q + (1u << 20));
+                need(have);
+            }
             const int32_t bs = rd_i32(p + q);
             if (bs < 32 || (size_t)bs > size - q - 4) throw FormatError("Failed to parse record");
             const Record rec{p + q, p + q + 4 + (size_t)bs};
             // the variable-length fields must fit the record: qname, cigar, packed seq, qual
             const int32_t l_seq = rec.l_seq();
             if (l_seq < 0) throw FormatError("Failed to parse record");
-            const uint64_t need = 32ull + rec.l_read_name() + 4ull * rec.n_cigar() +
-                                  ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
-            if (need > (uint64_t)bs) throw FormatError("Failed to parse record");
+            const uint64_t need_bytes = 32ull + rec.l_read_name() + 4ull * rec.n_cigar() +
+                                        ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+            if (need_bytes > (uint64_t)bs) throw FormatError("Failed to parse record");
             records.push_back(rec);
             q += 4 + (size_t)bs;
         }
+        need(size);
     }
 };
 

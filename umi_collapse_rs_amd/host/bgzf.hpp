@@ -125,52 +125,104 @@ inline void parallel_for(size_t n, unsigned threads, const std::function<void(si
     if (failed) throw IoError(err);
 }
 
-// Whole-file BGZF decompression: scan the block headers (BSIZE in the BC subfield),
-// read ISIZE from each trailer, inflate all blocks in parallel into one buffer.
-inline Bytes decompress(const Bytes &in, unsigned threads)
+// Whole-file BGZF decompression: scan the block headers (BSIZE in the BC subfield), read ISIZE from
+// each trailer, inflate all blocks in parallel into one buffer -- a run of blocks per task, one
+// inflate state per run.  The caller may walk the buffer behind the inflate threads: wait(upto)
+// returns once every byte before `upto` is there (the BAM parse, sequential by nature, then costs
+// no time of its own).
+class Inflater
 {
-    std::vector<BlockRef> blocks;
-    size_t off = 0, total = 0;
-    while (off < in.size()) {
-        if (in.size() - off < 18 || in[off] != 0x1f || in[off + 1] != 0x8b || in[off + 2] != 8 || !(in[off + 3] & 4))
-            throw IoError("not a BGZF block at offset " + std::to_string(off));
-        const uint32_t xlen = in[off + 10] | (in[off + 11] << 8);
-        size_t x = off + 12;
-        const size_t xend = x + xlen;
-        if (xend > in.size()) throw IoError("truncated BGZF block");
-        uint32_t bsize = 0;
-        while (x + 4 <= xend) {
-            const uint32_t slen = in[x + 2] | (in[x + 3] << 8);
-            if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= xend)
-                bsize = (in[x + 4] | (in[x + 5] << 8)) + 1u;
-            x += 4 + (size_t)slen;
+  public:
+    Bytes out;
+
+    Inflater(const Bytes &in, unsigned threads) : in_(in)
+    {
+        size_t off = 0, total = 0;
+        while (off < in.size()) {
+            if (in.size() - off < 18 || in[off] != 0x1f || in[off + 1] != 0x8b || in[off + 2] != 8 || !(in[off + 3] & 4))
+                throw IoError("not a BGZF block at offset " + std::to_string(off));
+            const uint32_t xlen = in[off + 10] | (in[off + 11] << 8);
+            size_t x = off + 12;
+            const size_t xend = x + xlen;
+            if (xend > in.size()) throw IoError("truncated BGZF block");
+            uint32_t bsize = 0;
+            while (x + 4 <= xend) {
+                const uint32_t slen = in[x + 2] | (in[x + 3] << 8);
+                if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= xend)
+                    bsize = (in[x + 4] | (in[x + 5] << 8)) + 1u;
+                x += 4 + (size_t)slen;
+            }
+            // a block holds its header, the extra field and the 8-byte trailer (CRC32, ISIZE) at least
+            if (!bsize || bsize > in.size() - off || (size_t)bsize < (xend - off) + 8)
+                throw IoError("truncated BGZF block");
+            const size_t tail = off + bsize - 8;
+            const uint32_t isize = in[tail + 4] | (in[tail + 5] << 8) | (in[tail + 6] << 16) | ((uint32_t)in[tail + 7] << 24);
+            // (a BGZF block inflates to at most 64 KiB; a larger ISIZE is a corrupt trailer, and the
+            // sum would size the output buffer)
+            if (isize > 0x10000u) throw IoError("Failed to parse record: corrupt BGZF block");
+            blocks_.push_back({xend, (uint32_t)(tail - xend), isize, total});
+            total += isize;
+            off += bsize;
         }
-        // a block holds its header, the extra field and the 8-byte trailer (CRC32, ISIZE) at least
-        if (!bsize || bsize > in.size() - off || (size_t)bsize < (xend - off) + 8)
-            throw IoError("truncated BGZF block");
-        const size_t tail = off + bsize - 8;
-        const uint32_t isize = in[tail + 4] | (in[tail + 5] << 8) | (in[tail + 6] << 16) | ((uint32_t)in[tail + 7] << 24);
-        // (a BGZF block inflates to at most 64 KiB; a larger ISIZE is a corrupt trailer, and the
-        // sum would size the output buffer)
-        if (isize > 0x10000u) throw IoError("Failed to parse record: corrupt BGZF block");
-        blocks.push_back({xend, (uint32_t)(tail - xend), isize, total});
-        total += isize;
-        off += bsize;
+        out.resize(total); // (not zeroed: the inflate threads are the first to touch it)
+        base_ = out.data(); // (the caller may swap `out` away while the threads run: they write through this)
+        total_ = total;
+        n_runs_ = (blocks_.size() + RUN - 1) / RUN;
+        done_.reset(new std::atomic<int>[n_runs_ + 1]);
+        for (size_t r = 0; r <= n_runs_; r++) done_[r].store(0);
+        driver_ = std::thread([this, threads] {
+            try {
+                parallel_for(n_runs_, threads, [this](size_t r) { inflate_run(r); });
+            } catch (const std::exception &e) {
+                error_ = e.what();
+                failed_.store(true, std::memory_order_release);
+            }
+        });
     }
-    Bytes out(total); // (not zeroed: the inflate threads are the first to touch it)
-    // a run of blocks per task, one inflate state per run
-    const size_t run = 16, n_runs = (blocks.size() + run - 1) / run;
-    parallel_for(n_runs, threads, [&](size_t r) {
+    ~Inflater()
+    {
+        if (driver_.joinable()) driver_.join();
+    }
+    Inflater(const Inflater &) = delete;
+    Inflater &operator=(const Inflater &) = delete;
+
+    // every byte before `upto` (clamped to the size) is inflated when this returns
+    void wait(size_t upto)
+    {
+        upto = std::min(upto, total_);
+        while (ready_ < upto) {
+            if (failed_.load(std::memory_order_acquire)) finish();
+            if (cursor_ < n_runs_ && done_[cursor_].load(std::memory_order_acquire)) {
+                cursor_++;
+                const size_t next_block = std::min(blocks_.size(), cursor_ * RUN);
+                ready_ = next_block < blocks_.size() ? blocks_[next_block].out_off : total_;
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    }
+    // all of it; rethrows what an inflate thread ran into
+    void finish()
+    {
+        if (driver_.joinable()) driver_.join();
+        if (failed_) throw IoError(error_);
+        ready_ = total_;
+    }
+
+  private:
+    static constexpr size_t RUN = 16;
+    void inflate_run(size_t r)
+    {
         z_stream zs;
         std::memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, -15) != Z_OK) throw IoError("inflateInit2 failed");
-        for (size_t i = r * run; i < std::min(blocks.size(), (r + 1) * run); i++) {
-            const BlockRef &b = blocks[i];
+        for (size_t i = r * RUN; i < std::min(blocks_.size(), (r + 1) * RUN); i++) {
+            const BlockRef &b = blocks_[i];
             if (b.out_len == 0) continue;
-            if (i != r * run) inflateReset2(&zs, -15);
-            zs.next_in = const_cast<Bytef *>(in.data() + b.in_off);
+            if (i != r * RUN) inflateReset2(&zs, -15);
+            zs.next_in = const_cast<Bytef *>(in_.data() + b.in_off);
             zs.avail_in = b.in_len;
-            zs.next_out = out.data() + b.out_off;
+            zs.next_out = base_ + b.out_off;
             zs.avail_out = b.out_len;
             const int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.avail_out != 0) {
@@ -179,8 +231,24 @@ inline Bytes decompress(const Bytes &in, unsigned threads)
             }
         }
         inflateEnd(&zs);
-    });
-    return out;
+        done_[r].store(1, std::memory_order_release);
+    }
+
+    const Bytes &in_;
+    std::vector<BlockRef> blocks_;
+    size_t n_runs_ = 0, cursor_ = 0, ready_ = 0, total_ = 0;
+    uint8_t *base_ = nullptr;
+    std::unique_ptr<std::atomic<int>[]> done_;
+    std::atomic<bool> failed_{false};
+    std::string error_;
+    std::thread driver_;
+};
+
+inline Bytes decompress(const Bytes &in, unsigned threads)
+{
+    Inflater inf(in, threads);
+    inf.finish();
+    return std::move(inf.out);
 }
 
 // BGZF compression of a stream given as pieces (the header, runs of surviving records: nothing is

@@ -365,10 +365,13 @@ int main(int argc, char **argv)
         static umi::bgzf::Bytes raw;
         raw = umi::bgzf::read_file(args.input, args.num_threads);
         lap("read");
-        in.data = umi::bgzf::decompress(raw, args.num_threads);
-        lap("inflate");
-        in.parse();
-        lap("parse");
+        {
+            umi::bgzf::Inflater inflater(raw, args.num_threads); // (the parse walks behind the inflate threads)
+            in.data.swap(inflater.out);                          // (same storage: the threads write through their pointer)
+            in.parse_behind([&](size_t upto) { inflater.wait(upto); });
+            inflater.finish();
+        }
+        lap("inflate+parse");
         const double t_read = now_s();
 
         // ---- staging: deduplicate_sam.rs:93-177, in three passes so that --num-threads helps:
