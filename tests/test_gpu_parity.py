@@ -538,11 +538,12 @@ def test_segment_index_counting_sort_and_union_variants(L, k, n_raw, n_frac):
     c = umi.Context(0)
     try:
         ref = None
-        for lds, unite, ckey in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (0, 0, 0)):
+        for lds, unite, ckey, sliced in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1), (1, 0, 1, 1), (0, 1, 1, 0), (0, 0, 0, 0)):
             if True:
                 c.set_option("seg_lds", lds)
                 c.set_option("seg_unite", unite)
                 c.set_option("seg_ckey", ckey)  # compare keys (3 bits per base outside the bin) or filter keys
+                c.set_option("seg_sliced", sliced)  # 64 columns at a time from ballots, or a broadcast per column
                 st = check_against_oracle(c, keys, nm, fr, off, L, k)
                 assert st["n_edges"] > 0
                 ref = ref or st

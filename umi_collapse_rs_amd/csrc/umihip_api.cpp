@@ -202,6 +202,7 @@ struct umi_ctx {
     uint32_t table_pieces = 1; // many buckets: the table is walked, uploaded and handed to the fused kernel in
                                // this many pieces (measured on 10^5 positions: one launch 0.13 ms, four 0.24)
     bool seg_ckey = true;    // its pair kernel compares 3-bit-per-base compare keys where they fit 32 bits
+    bool seg_sliced = true;  // ... 64 columns at a time from ballots of the columns' code bits (k <= 3)
     bool seg_unite = true;   // its pair kernel unites symmetric pairs on the spot (batched directional path)
     bool seg_lds = true;     // counting sort of the partition through per-block LDS histograms (where
                              // every part has at most SEG_LDS_BINS bins), else one atomic per entry
@@ -626,6 +627,7 @@ class Pipeline {
             seg.key_words = n_words;
             seg.full_umi_len = umi_len;
             seg.use_ckey = key32 && ctx->seg_ckey && pl.seg_max_rest <= 10 ? 1u : 0u;
+            seg.col_sliced = ctx->seg_sliced ? 1u : 0u;
             if (ctx->seg_lds && pl.seg_max_bins <= SEG_LDS_BINS && !pl.seg_blocks.empty()) {
                 seg.blocks = d_seg_blocks;
                 seg.n_blocks = (uint32_t)pl.seg_blocks.size();
@@ -1760,6 +1762,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->table_pieces = (uint32_t)value;
     } else if (!strcmp(name, "seg_ckey")) {
         ctx->seg_ckey = value != 0;
+    } else if (!strcmp(name, "seg_sliced")) {
+        ctx->seg_sliced = value != 0;
     } else if (!strcmp(name, "seg_unite")) {
         ctx->seg_unite = value != 0;
     } else if (!strcmp(name, "seg_lds")) {

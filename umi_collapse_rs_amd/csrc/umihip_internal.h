@@ -256,6 +256,7 @@ struct SegArgs {
     int full_umi_len;       // ... and the whole length of such keys (the N-code check of the entry pass)
     uint32_t use_ckey; // 32-bit keys: the pair kernel compares the records' compare keys (every part of
                        // every segment leaves at most 10 bases outside its bins)
+    uint32_t col_sliced; // ... 64 columns at a time, bit-sliced (columns64_sliced), where k <= 3; 0: a broadcast per column
 };
 // exclusive scan of the bin counts -> bin_start, task list, counters[CNT_SEG_TASKS / _PAIRS];
 // then every entry of a segment is copied to its position in each part's sub-bucket order

@@ -491,6 +491,60 @@ __device__ __forceinline__ uint32_t columns32(KeyT x, KeyT ky, int k, uint32_t l
     return h;
 }
 
+// The same 64 columns against this lane's row, bit-sliced (compare keys, k <= 3): per base of the
+// compare key the two low bits of the columns' codes become two wave ballots (bit j = column j), the
+// lane XORs them with its own row's bits (as 0 / ~0 masks) -- a mismatch of the base where either
+// differs (the third code bit is the xor of the two: src/utils/read.rs:23-31) -- and feeds sticky
+// counters "more than l bases differ so far" through v_bitop3: fourteen instructions per base and
+// 64 pairs at k = 1, 84 for the six compared bases of a 12-bp position, where the broadcast loop
+// above takes 320.  Bit j of the result: at most K bases of column j differ from the row.
+template <int K, int NB> __device__ __forceinline__ unsigned long long columns64_sliced(uint32_t x, uint32_t ky)
+{
+    uint32_t cl[K + 1], ch[K + 1];
+#pragma unroll
+    for (int l = 0; l <= K; l++) cl[l] = ch[l] = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const unsigned long long p0 = __ballot((ky & (1u << (3 * b))) != 0u), p1 = __ballot((ky & (2u << (3 * b))) != 0u);
+        const uint32_t r0 = (uint32_t)((int32_t)(x << (31 - 3 * b)) >> 31), r1 = (uint32_t)((int32_t)(x << (30 - 3 * b)) >> 31);
+        const uint32_t dl = BITOP3((uint32_t)p0 ^ r0, (uint32_t)p1, r1, TT_A | (TT_B ^ TT_C));
+        const uint32_t dh = BITOP3((uint32_t)(p0 >> 32) ^ r0, (uint32_t)(p1 >> 32), r1, TT_A | (TT_B ^ TT_C));
+#pragma unroll
+        for (int l = K; l >= 1; l--) {
+            cl[l] = BITOP3(cl[l], cl[l - 1], dl, TT_A | (TT_B & TT_C));
+            ch[l] = BITOP3(ch[l], ch[l - 1], dh, TT_A | (TT_B & TT_C));
+        }
+        cl[0] |= dl;
+        ch[0] |= dh;
+    }
+    return ~(((unsigned long long)ch[K] << 32) | cl[K]);
+}
+template <int K> __device__ __forceinline__ unsigned long long columns64_sliced_nb(uint32_t x, uint32_t ky, int nb)
+{
+    switch (nb) { // (wave-uniform: the bases a compare key holds)
+    case 1: return columns64_sliced<K, 1>(x, ky);
+    case 2: return columns64_sliced<K, 2>(x, ky);
+    case 3: return columns64_sliced<K, 3>(x, ky);
+    case 4: return columns64_sliced<K, 4>(x, ky);
+    case 5: return columns64_sliced<K, 5>(x, ky);
+    case 6: return columns64_sliced<K, 6>(x, ky);
+    case 7: return columns64_sliced<K, 7>(x, ky);
+    case 8: return columns64_sliced<K, 8>(x, ky);
+    case 9: return columns64_sliced<K, 9>(x, ky);
+    default: return columns64_sliced<K, 10>(x, ky);
+    }
+}
+__device__ __forceinline__ unsigned long long columns64_sliced_k(uint32_t x, uint32_t ky, int k, int nb)
+{
+    switch (k) {
+    case 0: return columns64_sliced_nb<0>(x, ky, nb);
+    case 1: return columns64_sliced_nb<1>(x, ky, nb);
+    case 2: return columns64_sliced_nb<2>(x, ky, nb);
+    default: return columns64_sliced_nb<3>(x, ky, nb);
+    }
+}
+__device__ __forceinline__ unsigned long long columns64_sliced_k(uint64_t, uint64_t, int, int) { return 0ull; } // (never: CK is 32-bit)
+
 // ILP unions per lane, their steps interleaved: a union is a chain of dependent scattered accesses
 // (a load or a compare-and-swap per step, each a trip to the memory side), and a wave waits for
 // the longest chain among its lanes; with ILP chains per lane in flight the trips of the others
@@ -574,6 +628,8 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
 #pragma unroll
     for (int j = 0; j < SEG_MAX_PARTS - 1; j++) dup_mask[j] = KeyT(0);
     uint32_t have_seg = SEG_NONE, have_part = 0;
+    int ck_bases = 0;
+    const bool sliced = a.k <= 3 && g.col_sliced != 0;
     uint32_t nq = 0; // queued hits (wave-uniform); the queue outlives a task
 
     // The queued hits, ILP per lane at a time: both records again (L2), the dedupe rule (a pair
@@ -713,6 +769,7 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                     dup_mask[j] = (uint32_t)j < my_part ? (KeyT)sd->mask[j] : KeyT(0);
                 have_seg = seg;
                 have_part = my_part;
+                ck_bases = __builtin_amdgcn_readfirstlane(g.umi_len - (int)sd->nb[my_part]); // bases a compare key holds
             }
             for (uint32_t c0 = col0; c0 < col1; c0 += 64) {
                 // (a task of several tiles -- a sub-bucket beyond 1025 entries: the next 64 columns
@@ -721,10 +778,15 @@ __global__ __launch_bounds__(64) void seg_pair_kernel(PairArgs a, SegArgs g, flo
                 KeyT kn = pad_col<KeyT>();
                 if (c0 + 64u < col1 && cn_pos < end) kn = loop_key<CK>(sub[cn_pos]);
                 const uint32_t nc = min(64u, end - c0);
-                uint32_t hlo = 0, hhi = 0; // bit j: this lane's row is within k of column j of the tile
-                hlo = columns32<CK, 0>(x, ky, a.k, lim2);
-                if (nc > 32) hhi = columns32<CK, 32>(x, ky, a.k, lim2);
-                unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
+                unsigned long long h; // bit j: this lane's row is within k of column j of the tile
+                if (CK && sliced) {
+                    h = columns64_sliced_k(x, ky, a.k, ck_bases);
+                } else {
+                    uint32_t hlo = 0, hhi = 0;
+                    hlo = columns32<CK, 0>(x, ky, a.k, lim2);
+                    if (nc > 32) hhi = columns32<CK, 32>(x, ky, a.k, lim2);
+                    h = ((unsigned long long)hhi << 32) | hlo;
+                }
                 // the columns this lane's row may pair with: inside the tile, and behind the row
                 // (position c0 + j > r, i.e. j > lane - (c0 - row0))
                 const int j_min = lane + 1 - (int)(c0 - row0);
