@@ -174,6 +174,9 @@ int umi_dedup_batch_wide_device(umi_ctx *ctx, const uint64_t *d_keys, const uint
  *      in canonical order, rep = file index of the read that represents it, bucket_off
  *      [*n_buckets + 1]; capacity n_reads (bucket_off: n_reads + 1), caller-owned.
  * UMI_ERR_CHAR for a character outside ATCGN (the reference panics, utils/mod.rs:77-79).
+ * n_reads < 2^30 per call (UMI_ERR_ARG beyond).  The smaller align_key_bits, the fewer passes the
+ * sort of the reads takes: where align_key_bits + 7 bits per 3 bases of UMI fit 64 bits (12-bp UMIs:
+ * up to 36 bits of alignment key) the reads are sorted once, on one composed key.
  * The _device form takes and leaves everything in device memory (one synchronisation inside for
  * the two counts); the plain form copies host arrays in and out around it. */
 int umi_stage_reads_device(umi_ctx *ctx, const uint64_t *d_align_key, int align_key_bits,
