@@ -118,6 +118,8 @@ const char *umi_last_error(void);
  *                    outside a bin fit 32 bits (0: the 2-bit filter keys)
  *   "seg_sliced"     0/1 (default 1): ... 64 columns of a tile at a time, from wave ballots of the columns'
  *                    code bits (k <= 3); 0: one broadcast column at a time
+ *   "spin_wait"      0/1 (default 1): the end of a batched call is seen by watching a word in pinned host
+ *                    memory that the stream's last kernel writes (0: hipStreamSynchronize)
  *   "table_pieces"   1..64 (default 1): a bucket table of more than 4096 positions is walked, uploaded
  *                    and handed to the fused kernel in this many pieces
  *   "split_min"      multi-device contexts, see umi_ctx_create_multi

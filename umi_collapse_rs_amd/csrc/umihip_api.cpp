@@ -230,7 +230,11 @@ struct umi_ctx {
     uint64_t *h_boff = nullptr;               // pinned staging of the bucket table
     size_t h_boff_cap = 0;
     PinnedBuf h_tasks;                        // pinned staging of the bit-sliced tile-task lists
-    unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES)
+    unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES), then, in a line of
+                                              // its own, the sequence number of the last copy that has arrived
+    unsigned long long ctrl_seq = 0;          // ... and of the last copy asked for
+    bool spin_wait = true;                    // watch that number instead of hipStreamSynchronize (option "spin_wait")
+    unsigned long long *h_seq() const { return h_counters + CTRL_BYTES / sizeof(unsigned long long); }
     uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
     uint32_t *d_changed() const { return (uint32_t *)(counters.as<unsigned long long>() + CNT_COUNT); }
     static constexpr int N_EVENTS = 10;
@@ -495,8 +499,24 @@ class Pipeline {
 
     int read_control()
     {
-        HIP_TRY(launch_control_to_host(d_cnt, ctx->h_counters, CTRL_BYTES, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (ctx->spin_wait && !prof) { // (the phase profile reads events afterwards: they want the runtime's wait)
+            // The control block's arrival is the end of the stream's work: watched for here (bounded: a
+            // stream in error never delivers, and the runtime's wait below reports why)
+            const unsigned long long seq = ++ctx->ctrl_seq;
+            HIP_TRY(launch_control_to_host(d_cnt, ctx->h_counters, CTRL_BYTES, s, ctx->h_seq(), seq));
+            const auto t0 = std::chrono::steady_clock::now();
+            bool there = false;
+            for (unsigned spins = 0; !there; spins++) {
+                there = __atomic_load_n(ctx->h_seq(), __ATOMIC_ACQUIRE) == seq;
+                if (!there && (spins & 1023u) == 1023u &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                    break;
+            }
+            if (!there) HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(launch_control_to_host(d_cnt, ctx->h_counters, CTRL_BYTES, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         const unsigned long long bad =
             ctx->h_counters[CNT_ERROR] + (ctx->h_counters[CNT_RISES] - ctx->h_counters[CNT_START_RISES]);
         if (bad)
@@ -1657,7 +1677,8 @@ int umi_ctx_create(int device_id, umi_ctx **out)
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (err == hipSuccess)
-        err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES);
+        err = hipHostMalloc((void **)&ctx->h_counters, CTRL_BYTES + 64);
+    if (err == hipSuccess) *ctx->h_seq() = 0;
     for (int i = 0; i < umi_ctx::N_EVENTS && err == hipSuccess; i++) err = hipEventCreate(&ctx->ev[i]);
 
     if (err != hipSuccess) {
@@ -1762,6 +1783,8 @@ int umi_ctx_set_option(umi_ctx *ctx, const char *name, int64_t value)
         ctx->table_pieces = (uint32_t)value;
     } else if (!strcmp(name, "seg_ckey")) {
         ctx->seg_ckey = value != 0;
+    } else if (!strcmp(name, "spin_wait")) {
+        ctx->spin_wait = value != 0;
     } else if (!strcmp(name, "seg_sliced")) {
         ctx->seg_sliced = value != 0;
     } else if (!strcmp(name, "seg_unite")) {

@@ -332,7 +332,9 @@ struct CollapseDesc {
     uint32_t *changed;       // the rounds' flags in the control block
 };
 // bytes (a multiple of 8) of the control block to its pinned, device-visible host mirror
-hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes, hipStream_t s);
+// h_seq (pinned, may be null): set to seq once the block has arrived
+hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes, hipStream_t s,
+                                  unsigned long long *h_seq = nullptr, unsigned long long seq = 0);
 // ... phase by phase: comp[v] = root of v in place and lab[v] = v; round `round` along the
 // one-way pairs (a no-op once round - 1 was quiet); label = lab[comp[v]], kept, root, survivors
 hipError_t launch_collapse_flatten(const CollapseDesc &d, hipStream_t s);

@@ -447,6 +447,8 @@ int main(int argc, char **argv)
         umi::bgzf::Bytes umis;
         I32s sc;
         std::vector<uint8_t> fits(T, 1);
+        std::vector<int64_t> c_min(T, INT64_MAX), c_max(T, INT64_MIN); // coordinates and (ref, strand) codes seen, per thread
+        std::vector<uint64_t> rs_max(T, 0);
         if (gpu_stage) {
             akey.resize(n_rec);
             umis.resize((size_t)n_rec * umi_length);
@@ -487,7 +489,10 @@ int main(int argc, char **argv)
                     // Alignment{strand, coord, ref} in 64 bits: ref id (31) | strand (1) | coordinate (32)
                     const int64_t c = (int64_t)ii.coord;
                     if (c < INT32_MIN || c > INT32_MAX) fits[t] = 0;
-                    akey[ri] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c;
+                    c_min[t] = std::min(c_min[t], c);
+                    c_max[t] = std::max(c_max[t], c);
+                    rs_max[t] = std::max(rs_max[t], ii.ref_strand);
+                    akey[ri] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c; // (packed tighter below)
                     std::memcpy(&umis[(size_t)ri * umi_length], q + at, umi_length);
                     sc[ri] = ii.score;
                 }
@@ -565,6 +570,26 @@ int main(int argc, char **argv)
             }
             rep64.resize(ns);
             for (uint8_t f : fits) gpu_stage = gpu_stage && f;
+            // The alignment key in as few bits as the file needs -- (ref, strand) code above the coordinate
+            // counted from the smallest one -- so that with the UMI it fits the device sort's one 64-bit key
+            // (a human genome: 6 + 28 bits, and 28 more for 12 bases)
+            int akey_bits = 64;
+            if (gpu_stage && ns) {
+                const int64_t lo = *std::min_element(c_min.begin(), c_min.end()), hi = *std::max_element(c_max.begin(), c_max.end());
+                const uint64_t rs_hi = *std::max_element(rs_max.begin(), rs_max.end());
+                auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; };
+                const int cbits = bits_of((uint64_t)(hi - lo)), rbits = bits_of(rs_hi);
+                if (cbits + rbits < 64) {
+                    akey_bits = cbits + rbits;
+                    const size_t per = (ns + T - 1) / T;
+                    umi::bgzf::parallel_for(T, T, [&](size_t t) {
+                        for (size_t j = t * per; j < std::min(ns, (t + 1) * per); j++) {
+                            const uint64_t a = akey[j];
+                            akey[j] = ((a >> 32) << cbits) | (uint64_t)((int64_t)(int32_t)(uint32_t)a - lo);
+                        }
+                    });
+                }
+            }
             lap("fill");
             if (!gpu_stage) encode_all(); // (a coordinate beyond 32 bits: the host staging takes the file)
             if (gpu_stage) {
@@ -572,7 +597,7 @@ int main(int argc, char **argv)
                 lap("wait-gpu");
                 keys.resize(ns * n_words); nmask.resize(ns * n_words); freq.resize(ns); off.resize(ns + 1);
                 uint64_t ne = 0, nbk = 0;
-                if (lib.stage_reads(ctx, akey.data(), 64, umis.data(), sc.data(), ns, (int)umi_length, n_words, merge != 0 ? 1 : 0,
+                if (lib.stage_reads(ctx, akey.data(), akey_bits, umis.data(), sc.data(), ns, (int)umi_length, n_words, merge != 0 ? 1 : 0,
                                     keys.data(), nmask.data(), freq.data(), rep64.data(), off.data(), &ne, &nbk) != UMI_OK)
                     die(lib.last_error());
                 lap("stage-call");
