@@ -1125,8 +1125,10 @@ class Pipeline {
                     HIP_TRY(launch_uf_union_list(ctx->edges.as<uint2>(), d_cnt, cap_used, d_label, cap_used, s));
                 const CollapseDesc cd = collapse_desc();
                 HIP_TRY(launch_collapse_flatten(cd, s));
-                for (int r = 0; r < DAG_ROUNDS; r++) HIP_TRY(launch_collapse_round(cd, r, s));
-                HIP_TRY(launch_collapse_finalize(cd, s));
+                // (the last of them as a check beside the finalize pass: in the common case it would change
+                // nothing, and the kept mask stands)
+                for (int r = 0; r < DAG_ROUNDS - 1; r++) HIP_TRY(launch_collapse_round(cd, r, s));
+                HIP_TRY(launch_collapse_finalize(cd, s, DAG_ROUNDS - 1));
             } else { // no pair of this call reaches the edge list: every entry outside the fused buckets survives
                 HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
             }

@@ -112,6 +112,21 @@ __device__ __forceinline__ bool one_way_round(const CollapseArgs &a)
     return any;
 }
 
+// The same walk without a store: would a round still move a label?  (Rides in the finalize launch as
+// blocks of its own, first_block .. gridDim.x - 1: lab[] is only read there, by both.)
+__device__ __forceinline__ bool one_way_check(const CollapseArgs &a, uint32_t first_block)
+{
+    const unsigned long long ne = a.counters[CNT_EDGES];
+    const uint32_t E = ne < a.edge_cap ? (uint32_t)ne : a.edge_cap;
+    const uint32_t n_blocks = gridDim.x - first_block, me = blockIdx.x - first_block;
+    bool any = false;
+    for (uint32_t e = me * blockDim.x + threadIdx.x; e < E; e += n_blocks * blockDim.x) {
+        const uint2 uv = a.edges[e];
+        if (!(uv.x & SYM_FLAG)) any |= a.lab[a.parent[uv.x]] < a.lab[a.parent[uv.y]];
+    }
+    return any;
+}
+
 __device__ __forceinline__ unsigned int finalize_entry(const CollapseArgs &a, uint32_t i)
 {
     const uint32_t l = a.lab[a.parent[i]]; // label[v] = lab[comp[v]] (directional.rs:30-54,78-88)
@@ -138,11 +153,27 @@ __global__ __launch_bounds__(256) void dag_flat_hook_kernel(CollapseArgs a, int 
 
 __global__ __launch_bounds__(256) void uf_flatten_kernel(CollapseArgs a) { collapse_entries(a, [&](uint32_t v) { flatten_entry(a.parent, a.lab, v); }); }
 
-// kept / root / survivor count of the entries of ranges (null: all n) from comp and lab
-__global__ __launch_bounds__(256) void map_finalize_kernel(CollapseArgs a)
+// kept / root / survivor count of the entries of ranges (null: all n) from comp and lab, by the first
+// entry_blocks blocks; the blocks behind them (check_round >= 0) look whether round check_round would
+// still move a label -- the last of the rounds enqueued ahead of the host's look changes nothing in
+// the common case and is there only to say so: as a check beside the finalize pass it costs no launch
+// of its own (the result stands if changed[check_round] stays 0; else the host runs on and finalizes again)
+__global__ __launch_bounds__(256) void map_finalize_kernel(CollapseArgs a, uint32_t entry_blocks, int check_round)
 {
+    if (blockIdx.x >= entry_blocks) {
+        if (check_round > 0 && a.changed[check_round - 1] == 0) return; // (the round before was quiet already)
+        if (one_way_check(a, entry_blocks)) a.changed[check_round] = 1;
+        return;
+    }
     unsigned int cnt = 0;
-    collapse_entries(a, [&](uint32_t i) { cnt += finalize_entry(a, i); });
+    if (a.ranges) {
+        for (uint32_t r = blockIdx.x; r < a.n_ranges; r += entry_blocks) {
+            const RangeTask rt = a.ranges[r];
+            for (uint32_t i = rt.start + threadIdx.x; i < rt.end; i += blockDim.x) cnt += finalize_entry(a, i);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += entry_blocks * blockDim.x) cnt += finalize_entry(a, i);
+    }
     block_count_add(cnt, &a.counters[CNT_KEPT]);
 }
 
@@ -229,10 +260,12 @@ hipError_t launch_collapse_round(const CollapseDesc &d, int round, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_collapse_finalize(const CollapseDesc &d, hipStream_t s)
+hipError_t launch_collapse_finalize(const CollapseDesc &d, hipStream_t s, int check_round)
 {
     if (d.n == 0 || (d.ranges && d.n_ranges == 0)) return hipSuccess;
-    map_finalize_kernel<<<entries_grid(d, 2048), 256, 0, s>>>(collapse_args(d));
+    const uint32_t entry_blocks = entries_grid(d, 2048);
+    const uint32_t check_blocks = check_round >= 0 ? grid_of(d.edge_cap, 256 * 8, 256) : 0u;
+    map_finalize_kernel<<<entry_blocks + check_blocks, 256, 0, s>>>(collapse_args(d), entry_blocks, check_round);
     return hipGetLastError();
 }
 

@@ -339,7 +339,9 @@ hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes
 // one-way pairs (a no-op once round - 1 was quiet); label = lab[comp[v]], kept, root, survivors
 hipError_t launch_collapse_flatten(const CollapseDesc &d, hipStream_t s);
 hipError_t launch_collapse_round(const CollapseDesc &d, int round, hipStream_t s);
-hipError_t launch_collapse_finalize(const CollapseDesc &d, hipStream_t s);
+// check_round >= 0: blocks of their own look, without a store, whether round check_round would still
+// move a label (changed[check_round])
+hipError_t launch_collapse_finalize(const CollapseDesc &d, hipStream_t s, int check_round = -1);
 // bits[i / 8] bit (i % 8) = kept[i] != 0, for i < n (ceil(n / 8) bytes written)
 hipError_t launch_pack_mask(const uint8_t *kept, uint64_t n, uint8_t *bits, hipStream_t s);
 
