@@ -398,6 +398,8 @@ class Pipeline {
     uint64_t task_counter = 0;    // running index over all tile tasks, for that split
     bool prune = false, drained = false, fused_ran = false, seg_timed = false;
     size_t zero_behind_control = 0; // bytes of the segment index's counters that sit behind the control block
+    uint32_t priv_blocks_for_collapse = 0; // blocks of the segment index's pair kernel whose private edge slots the
+                                           // collapse's flatten launch appends to the list (0: appended already)
     umi_stats st;
     unsigned long long *d_cnt = nullptr;
     size_t n_tasks = 0;              // tile tasks of the pair kernels (fused buckets excluded)
@@ -966,7 +968,11 @@ class Pipeline {
             HIP_TRY(launch_seg_pairs(a, seg, key32, percentage, part, n_parts, blocks, s));
             if (prof) HIP_TRY(hipEventRecord(ctx->ev[8], s));
             seg_timed = true;
-            HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
+            // what the blocks still hold in their private slots: one-way pairs only when the symmetric
+            // ones were united where they were found, and then the collapse's flatten launch moves them
+            // to the list (collapse_desc); else two small launches here, ahead of the list's unions
+            priv_blocks_for_collapse = seg.uf_parent && mode == MODE_DIRECTIONAL ? blocks : 0u;
+            if (!priv_blocks_for_collapse) HIP_TRY(launch_seg_edge_append(a, seg, blocks, s));
             st.n_pair_launches += 1;
         }
 #ifdef UMIHIP_DEV
@@ -1006,7 +1012,7 @@ class Pipeline {
 
     void note_pair_counters()
     {
-        n_edges = ctx->h_counters[CNT_EDGES];
+        n_edges = ctx->h_counters[CNT_EDGES] + ctx->h_counters[CNT_EDGES_MOVED];
         n_direct = ctx->h_counters[CNT_UF_DIRECT];
         seg_tasks_made = ctx->h_counters[CNT_SEG_TASKS];
         st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
@@ -1102,6 +1108,11 @@ class Pipeline {
         d.root = d_root;
         d.counters = d_cnt;
         d.changed = ctx->d_changed();
+        if (priv_blocks_for_collapse) {
+            d.priv_edges = seg.priv_edges;
+            d.priv_cnt = seg.priv_cnt;
+            d.priv_blocks = priv_blocks_for_collapse;
+        }
         return d;
     }
     int run_one_sync()
@@ -1147,7 +1158,7 @@ class Pipeline {
             ctx->edge_capacity = cap;
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_EDGES], 0, 2 * sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(&d_cnt[CNT_KEPT], 0, sizeof(unsigned long long), s));
-            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UF_DIRECT], 0, sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(&d_cnt[CNT_UF_DIRECT], 0, 2 * sizeof(unsigned long long), s));
             HIP_TRY(hipMemsetAsync(d_changed, 0, CTRL_BYTES - CTRL_FLAGS_OFF, s)); // flags and sync words
             HIP_TRY(launch_iota(d_label, n, s)); // (the fused buckets' entries are finished: their labels are free)
         }

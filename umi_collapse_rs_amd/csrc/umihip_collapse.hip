@@ -47,7 +47,17 @@ struct CollapseArgs {
     uint32_t *root;          // may be null
     unsigned long long *counters;
     uint32_t *changed;       // [MAX_ROUNDS_PER_SYNC] round r moved a label
+    const uint2 *priv_edges; // the pair kernel's private slots (may be null), priv_blocks of SEG_PRIV_CAP edges
+    const uint32_t *priv_cnt;
+    uint32_t priv_blocks;
 };
+
+// the length of the list: what the pair kernels appended themselves and what the flatten launch moved behind it
+__device__ __forceinline__ uint32_t list_length(const CollapseArgs &a)
+{
+    const unsigned long long ne = a.counters[CNT_EDGES] + a.counters[CNT_EDGES_MOVED];
+    return ne < a.edge_cap ? (uint32_t)ne : a.edge_cap;
+}
 
 template <class F> __device__ __forceinline__ void collapse_entries(const CollapseArgs &a, F f)
 {
@@ -85,8 +95,7 @@ __device__ __forceinline__ void flatten_entry(uint32_t *parent, uint32_t *lab, u
 // Returns whether this thread saw a label to move.  Every lane of a wave makes the same trips.
 __device__ __forceinline__ bool one_way_round(const CollapseArgs &a)
 {
-    const unsigned long long ne = a.counters[CNT_EDGES];
-    const uint32_t E = ne < a.edge_cap ? (uint32_t)ne : a.edge_cap;
+    const uint32_t E = list_length(a);
     constexpr uint32_t PER_BLOCK = 256 * 8;
     const uint32_t active = min(gridDim.x, (E + PER_BLOCK - 1) / PER_BLOCK);
     bool any = false;
@@ -116,8 +125,7 @@ __device__ __forceinline__ bool one_way_round(const CollapseArgs &a)
 // blocks of its own, first_block .. gridDim.x - 1: lab[] is only read there, by both.)
 __device__ __forceinline__ bool one_way_check(const CollapseArgs &a, uint32_t first_block)
 {
-    const unsigned long long ne = a.counters[CNT_EDGES];
-    const uint32_t E = ne < a.edge_cap ? (uint32_t)ne : a.edge_cap;
+    const uint32_t E = list_length(a);
     const uint32_t n_blocks = gridDim.x - first_block, me = blockIdx.x - first_block;
     bool any = false;
     for (uint32_t e = me * blockDim.x + threadIdx.x; e < E; e += n_blocks * blockDim.x) {
@@ -151,7 +159,60 @@ __global__ __launch_bounds__(256) void dag_flat_hook_kernel(CollapseArgs a, int 
     if (one_way_round(a)) a.changed[round] = 1;
 }
 
-__global__ __launch_bounds__(256) void uf_flatten_kernel(CollapseArgs a) { collapse_entries(a, [&](uint32_t v) { flatten_entry(a.parent, a.lab, v); }); }
+// The private slots to the list, 64 slots per block (blocks behind the flatten pass's own, in the same
+// launch: was a scan kernel and a move kernel, 11 us).  A block adds up the counts of the slots before
+// its group itself (at most 4,096 words), scans its own 64, and moves its slots' edges behind what the
+// list holds; the last group says how many there were in all.  Nobody writes CNT_EDGES meanwhile.
+constexpr uint32_t GATHER_SLOTS = 64;
+__device__ __forceinline__ void gather_private_edges(const CollapseArgs &a, uint32_t group)
+{
+    __shared__ unsigned long long wsum[4];
+    __shared__ uint32_t pre[GATHER_SLOTS + 1];
+    const uint32_t s0 = group * GATHER_SLOTS, s1 = min(a.priv_blocks, s0 + GATHER_SLOTS);
+    unsigned long long before = 0;
+    for (uint32_t i = threadIdx.x; i < s0; i += blockDim.x) before += a.priv_cnt[i];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = before;
+    if (threadIdx.x < 64) { // the group's own counts, exclusive
+        const uint32_t c = s0 + threadIdx.x < s1 ? min(a.priv_cnt[s0 + threadIdx.x], SEG_PRIV_CAP) : 0u;
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        pre[threadIdx.x] = incl - c;
+        if (threadIdx.x == 63) pre[GATHER_SLOTS] = incl;
+    }
+    __syncthreads();
+    const unsigned long long first = a.counters[CNT_EDGES] + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint2 *list = const_cast<uint2 *>(a.edges);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t j = wave; s0 + j < s1; j += blockDim.x >> 6) {
+        const uint32_t cnt = pre[j + 1] - pre[j];
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const unsigned long long pos = first + pre[j] + i;
+            if (pos < a.edge_cap) list[pos] = a.priv_edges[(size_t)(s0 + j) * SEG_PRIV_CAP + i];
+        }
+    }
+    if (s1 == a.priv_blocks && threadIdx.x == 0) a.counters[CNT_EDGES_MOVED] = first + pre[GATHER_SLOTS] - a.counters[CNT_EDGES];
+}
+
+__global__ __launch_bounds__(256) void uf_flatten_kernel(CollapseArgs a, uint32_t entry_blocks)
+{
+    if (blockIdx.x >= entry_blocks) {
+        gather_private_edges(a, blockIdx.x - entry_blocks);
+        return;
+    }
+    if (a.ranges) {
+        for (uint32_t r = blockIdx.x; r < a.n_ranges; r += entry_blocks) {
+            const RangeTask rt = a.ranges[r];
+            for (uint32_t i = rt.start + threadIdx.x; i < rt.end; i += blockDim.x) flatten_entry(a.parent, a.lab, i);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += entry_blocks * blockDim.x)
+            flatten_entry(a.parent, a.lab, i);
+    }
+}
 
 // kept / root / survivor count of the entries of ranges (null: all n) from comp and lab, by the first
 // entry_blocks blocks; the blocks behind them (check_round >= 0) look whether round check_round would
@@ -212,6 +273,9 @@ CollapseArgs collapse_args(const CollapseDesc &d)
     a.root = d.root;
     a.counters = d.counters;
     a.changed = d.changed;
+    a.priv_edges = d.priv_edges;
+    a.priv_cnt = d.priv_cnt;
+    a.priv_blocks = d.priv_blocks;
     return a;
 }
 
@@ -249,8 +313,11 @@ hipError_t launch_control_to_host(const void *d_ctrl, void *h_ctrl, size_t bytes
 
 hipError_t launch_collapse_flatten(const CollapseDesc &d, hipStream_t s)
 {
-    if (d.n == 0 || (d.ranges && d.n_ranges == 0)) return hipSuccess;
-    uf_flatten_kernel<<<entries_grid(d, 4096), 256, 0, s>>>(collapse_args(d));
+    const bool entries = !(d.n == 0 || (d.ranges && d.n_ranges == 0));
+    const uint32_t entry_blocks = entries ? entries_grid(d, 4096) : 0u;
+    const uint32_t gather_blocks = d.priv_blocks ? (d.priv_blocks + GATHER_SLOTS - 1) / GATHER_SLOTS : 0u;
+    if (entry_blocks + gather_blocks == 0) return hipSuccess;
+    uf_flatten_kernel<<<entry_blocks + gather_blocks, 256, 0, s>>>(collapse_args(d), entry_blocks);
     return hipGetLastError();
 }
 

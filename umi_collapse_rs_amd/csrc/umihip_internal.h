@@ -41,7 +41,9 @@ enum Counter : int {
     CNT_SEG_PAIRS = 13, // ... and the pairs inside its sub-buckets (what the pair kernel compares)
     CNT_KEPT_FUSED = 14, // survivors of the buckets the fused one-wave kernel finished by itself
     CNT_UF_DIRECT = 15, // symmetric pairs the segment index's pair kernel united on the spot (not in the list)
-    CNT_COUNT = 16,
+    CNT_EDGES_MOVED = 16, // edges the flatten launch moved from the pair kernel's private slots to the list, behind
+                          // the CNT_EDGES it found there (the list's length is the sum of the two)
+    CNT_COUNT = 17,
 };
 // The flags of the collapse rounds ("round r changed a label") sit behind the counters in the
 // same device block, so that one memset clears and one copy reads everything the host looks at.
@@ -330,6 +332,11 @@ struct CollapseDesc {
     uint32_t *root;
     unsigned long long *counters;
     uint32_t *changed;       // the rounds' flags in the control block
+    // what the segment index's pair kernel left in its blocks' private slots (one-way pairs only: the
+    // symmetric ones were united where they were found); the flatten launch appends them to the list
+    const uint2 *priv_edges = nullptr; // [priv_blocks * SEG_PRIV_CAP]
+    const uint32_t *priv_cnt = nullptr;
+    uint32_t priv_blocks = 0;
 };
 // bytes (a multiple of 8) of the control block to its pinned, device-visible host mirror
 // h_seq (pinned, may be null): set to seq once the block has arrived
