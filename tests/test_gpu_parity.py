@@ -451,6 +451,36 @@ def test_edge_list_overflow_is_transparent():
         c.close()
 
 
+@pytest.mark.parametrize("spin", [0, 1])
+def test_end_of_call_seen_by_the_runtime_or_by_watching_pinned_memory(spin):
+    """option spin_wait: the stream's last kernel writes a sequence word behind the control block in pinned
+    host memory (1, default) / hipStreamSynchronize (0) -- same results, also when the device-side outputs are
+    read straight after the call returns, and call after call on one context (the sequence goes on)."""
+    import torch
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(460 + spin)
+    c = umi.Context(0)
+    try:
+        c.set_option("spin_wait", spin)
+        dev = torch.device("cuda:0")
+        for rep in range(4):
+            keys, nm, fr, off = make_batch(rng, 200 + 50 * rep, 12, 50, err=0.05)
+            kb, nb_, fb, ob = make_batch(rng, 1, 12, 900, err=0.05, exact=True)  # one position for the segment index
+            keys = np.concatenate([keys, kb]); nm = np.concatenate([nm, nb_]); fr = np.concatenate([fr, fb])
+            off = np.concatenate([off, off[-1] + ob[1:]]).astype(np.uint64)
+            t_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+            t_fr = torch.from_numpy(fr).to(dev)
+            t_kept = torch.zeros(len(keys), dtype=torch.uint8, device=dev)
+            t_root = torch.zeros(len(keys), dtype=torch.int32, device=dev)
+            st = c.dedup_batch_device(t_keys.data_ptr(), 0, t_fr.data_ptr(), off, 12, t_kept.data_ptr(), t_root.data_ptr(),
+                                      k=1, stream=torch.cuda.current_stream().cuda_stream)
+            got_kept, got_root = t_kept.cpu().numpy(), t_root.cpu().numpy().view(np.uint32)
+            okept, oroot, _ = orc.dedup_batch(keys, None, fr, off, 12, 1)
+            assert (got_kept == okept).all() and (got_root == oroot).all() and st["n_kept"] == int(okept.sum())
+    finally:
+        c.close()
+
+
 def test_contract_violations_are_reported(ctx):
     import umi_collapse_rs_amd as umi
     from umi_collapse_rs_amd import _lib

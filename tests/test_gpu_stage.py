@@ -165,3 +165,36 @@ def test_staging_of_umis_of_any_length_against_the_definition(ctx, L, n_reads, n
     else:
         okept, oroot, _ = orc.dedup_batch(wk[:, 0], wm[:, 0], w_freq, w_off, L, 1)
     assert (kept == okept).all() and (root == oroot).all()
+
+
+@pytest.mark.parametrize("L,n_reads,shift,bits", [(12, 70_001, 1, 20), (12, 70_001, 0, 37), (9, 3_000, 3, 64), (16, 513, 2, 12),
+                                                   (12, 255, 0, 5), (7, 2, 1, 1)])
+def test_device_form_with_text_off_the_word_boundary_and_any_key_width(ctx, L, n_reads, shift, bits):
+    """The encode kernel takes the UMI text as whole words where it starts on a 4-byte boundary and byte by
+    byte where it does not (and for the file's last, partial chunk of 256 reads); the reads are sorted on one
+    composed key where align_key_bits + the packed UMI fit 64 bits (bits = 20, 12, 5, 1 here; 37 + 28 and 64
+    do not: a sort per key word).  Same entries every way."""
+    import torch
+    rng = np.random.default_rng(31 * L + n_reads + shift)
+    n_pos = max(1, min(n_reads // 20, (1 << min(bits, 20)) - 1))
+    pos, umi, score = make_reads(rng, n_reads, n_pos, L, 4, n_frac=0.004, sorted_file=False)
+    dev = torch.device("cuda", 0)
+    d_key = torch.from_numpy(pos.astype(np.int64)).to(dev)
+    raw = torch.zeros(len(umi) + 8, dtype=torch.uint8, device=dev)
+    raw[shift:shift + len(umi)] = torch.from_numpy(umi.copy()).to(dev)
+    d_score = torch.from_numpy(score).to(dev)
+    outs = [torch.zeros(n_reads, dtype=torch.int64, device=dev) for _ in range(3)]  # keys, nmask, rep
+    d_freq = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    ne, nb = ctx.stage_reads_device(d_key.data_ptr(), raw.data_ptr() + shift, d_score.data_ptr(), n_reads, L,
+                                    outs[0].data_ptr(), outs[1].data_ptr(), d_freq.data_ptr(), outs[2].data_ptr(),
+                                    d_off.data_ptr(), merge=1, align_key_bits=bits,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = orc.stage_reads(dense_ids(pos), umi, score, L, 1)
+    assert ne == len(want["keys"]) and nb == len(want["bucket_off"]) - 1
+    assert (outs[0][:ne].cpu().numpy().view(np.uint64) == want["keys"]).all()
+    assert (outs[1][:ne].cpu().numpy().view(np.uint64) == want["nmask"]).all()
+    assert (d_freq[:ne].cpu().numpy() == want["freq"]).all()
+    assert (outs[2][:ne].cpu().numpy().view(np.uint64) == want["rep"]).all()
+    assert (d_off[:nb + 1].cpu().numpy().view(np.uint64) == want["bucket_off"]).all()
