@@ -27,6 +27,7 @@ print("input: %d reads, %d positions, %.1f MB" % (reads, positions, os.path.gets
 def run(extra, env=None, label=""):
     e = dict(os.environ, UMICOLLAPSE_CLOCK="1")
     e.update(env or {})
+    time.sleep(1.0)  # (the driver puts the context of the run before away in the background: ~0.12 s of the next run's start)
     t0 = time.time()
     r = subprocess.run([CLI, "-i", src, "-o", dst, "--merge", "avgqual", "--num-threads", "16"] + extra,
                        capture_output=True, text=True, env=e)

@@ -459,6 +459,10 @@ int main(int argc, char **argv)
         const uint32_t chunk = (n_rec + T - 1) / T;
         umi::bgzf::parallel_for(T, T, [&](size_t t) {
             const uint32_t lo = (uint32_t)t * chunk, hi = std::min(n_rec, lo + chunk);
+            // (the thread's extremes in locals: sixteen threads updating neighbours of one cache line
+            // per read made this pass 0.27 s instead of 0.02)
+            int64_t my_c_min = INT64_MAX, my_c_max = INT64_MIN;
+            uint64_t my_rs_max = 0;
             for (uint32_t ri = lo; ri < hi; ri++) {
                 const umi::bam::Record &r = in.records[ri];
                 ReadInfo &ii = info[ri];
@@ -489,14 +493,17 @@ int main(int argc, char **argv)
                     // Alignment{strand, coord, ref} in 64 bits: ref id (31) | strand (1) | coordinate (32)
                     const int64_t c = (int64_t)ii.coord;
                     if (c < INT32_MIN || c > INT32_MAX) fits[t] = 0;
-                    c_min[t] = std::min(c_min[t], c);
-                    c_max[t] = std::max(c_max[t], c);
-                    rs_max[t] = std::max(rs_max[t], ii.ref_strand);
+                    my_c_min = std::min(my_c_min, c);
+                    my_c_max = std::max(my_c_max, c);
+                    my_rs_max = std::max(my_rs_max, ii.ref_strand);
                     akey[ri] = (ii.ref_strand << 32) | (uint64_t)(uint32_t)(int32_t)c; // (packed tighter below)
                     std::memcpy(&umis[(size_t)ri * umi_length], q + at, umi_length);
                     sc[ri] = ii.score;
                 }
             }
+            c_min[t] = my_c_min;
+            c_max[t] = my_c_max;
+            rs_max[t] = my_rs_max;
         });
         for (unsigned t = 0; t < T; t++) // the reference panics at the first offending read
             if (first_error[t] != UINT32_MAX) die(errors[t]);
