@@ -267,6 +267,14 @@ class Resident:
             s = c.dedup_batch_wide_device(self.d_keys.data_ptr(), 0, self.n_words, self.d_freq.data_ptr(), self.boff,
                                           wl["umi_len"], self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p,
                                           stream=self.stream)
+        elif self.coll:
+            # the call in two halves: the packing and the all-gather of the mask are enqueued behind its
+            # kernels while those run (~30 us of host time per step that would otherwise pass with the GPU
+            # idle); where the call has decisions to take on the host, begin runs it to its end
+            c.dedup_batch_device_begin(self.d_keys.data_ptr(), 0, self.d_freq.data_ptr(), self.boff, wl["umi_len"],
+                                       self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p, stream=self.stream,
+                                       d_bucket_off=self.d_boff.data_ptr())
+            s = None
         else:
             s = c.dedup_batch_device(self.d_keys.data_ptr(), 0, self.d_freq.data_ptr(), self.boff, wl["umi_len"],
                                      self.d_kept.data_ptr(), 0, k=wl["k"], percentage=self.p, stream=self.stream,
@@ -279,6 +287,8 @@ class Resident:
             c.pack_mask_device(self.d_kept.data_ptr(), self.n, self.gather_in[slot].data_ptr(), stream=self.stream)
             self.gather_work[slot] = self.dist.all_gather_into_tensor(self.gather_out[slot], self.gather_in[slot],
                                                                       async_op=True)  # RCCL over xGMI
+            if s is None:
+                s = c.dedup_batch_end()
         return s
 
     def drain_gathers(self):

@@ -251,6 +251,23 @@ int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uin
 int umi_pack_mask_device(umi_ctx *ctx, const uint8_t *d_kept, uint64_t n, uint8_t *d_bits,
                          void *hip_stream);
 
+/* The device-pointer call in two halves, for a host that has more to enqueue behind it (the packing
+ * and gathering of the kept mask of a multi-GPU step: ~30 us of host time that would otherwise pass
+ * with the GPU idle).  umi_dedup_batch_device_begin enqueues the call's work on hip_stream; where every
+ * position is the fused kernel's (no host decision is left: BASELINE configs 3, 4, 5) it returns
+ * without waiting -- d_kept / d_root are then final in stream order, and work enqueued on the same
+ * stream behind the call may read them -- otherwise it runs to its end like umi_dedup_batch_device_table.
+ * umi_dedup_batch_end waits for the call's end (if it is still out), reports a contract violation
+ * (UMI_ERR_ORDER) and fills stats.  One call may be out per context; any other call on the context
+ * that needs its workspace lets it end first (its result keeps waiting for umi_dedup_batch_end; a
+ * second begin replaces it). */
+int umi_dedup_batch_device_begin(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
+                                 const int32_t *d_freq, const uint64_t *bucket_off,
+                                 const uint64_t *d_bucket_off /* may be NULL */, uint64_t n_buckets,
+                                 int umi_len, int k, float percentage, int algo, int32_t adj_max_freq,
+                                 uint8_t *d_kept, uint32_t *d_root, void *hip_stream);
+int umi_dedup_batch_end(umi_ctx *ctx, umi_stats *stats);
+
 /* ---- one process, several GPUs, resident shards: the batched call on every device of a multi-device
  *      context at once -- device r works on its own arrays d_*[r] (its share of the positions: the
  *      iterations of src/deduplicate_sam.rs:207-233 share nothing but additive counters, so there is no

@@ -481,6 +481,76 @@ def test_end_of_call_seen_by_the_runtime_or_by_watching_pinned_memory(spin):
         c.close()
 
 
+def test_device_call_in_two_halves():
+    """umi_dedup_batch_device_begin / umi_dedup_batch_end: a batch of small positions is left on the stream
+    (work enqueued behind it on the same stream -- here the packing of the mask -- reads the final outputs),
+    a batch with a deep position runs to its end inside begin; both give the plain call's result.  A second
+    begin replaces the first; another call on the context lets a pending one end, its result keeps waiting; a
+    contract violation surfaces at end; end with nothing begun is an error."""
+    import torch
+    import umi_collapse_rs_amd as umi
+    rng = np.random.default_rng(4700)
+    dev = torch.device("cuda:0")
+    c = umi.Context(0)
+    try:
+        with pytest.raises(umi.UmiHipError):
+            c.dedup_batch_end()
+        small = make_batch(rng, 3000, 12, 25, err=0.05)
+        assert np.diff(small[3].astype(np.int64)).max() <= 128  # every position the fused kernel's: the end is deferred
+        kb, nb_, fb, ob = make_batch(rng, 1, 12, 900, err=0.05, exact=True)
+        deep = (np.concatenate([small[0], kb]), np.concatenate([small[1], nb_]), np.concatenate([small[2], fb]),
+                np.concatenate([small[3], small[3][-1] + ob[1:]]).astype(np.uint64))
+        stream = torch.cuda.current_stream().cuda_stream
+        for keys, nm, fr, off in (small, deep, small):
+            t_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+            t_fr = torch.from_numpy(fr).to(dev)
+            t_kept = torch.zeros(len(keys), dtype=torch.uint8, device=dev)
+            t_root = torch.zeros(len(keys), dtype=torch.int32, device=dev)
+            t_bits = torch.zeros((len(keys) + 7) // 8, dtype=torch.uint8, device=dev)
+            t_off = torch.from_numpy(off.view(np.int64)).to(dev)
+            c.dedup_batch_device_begin(t_keys.data_ptr(), 0, t_fr.data_ptr(), off, 12, t_kept.data_ptr(), t_root.data_ptr(),
+                                       k=1, stream=stream, d_bucket_off=t_off.data_ptr())
+            c.pack_mask_device(t_kept.data_ptr(), len(keys), t_bits.data_ptr(), stream=stream)  # behind the call, same stream
+            st = c.dedup_batch_end()
+            torch.cuda.synchronize()
+            okept, oroot, _ = orc.dedup_batch(keys, None, fr, off, 12, 1)
+            assert (t_kept.cpu().numpy() == okept).all() and (t_root.cpu().numpy().view(np.uint32) == oroot).all()
+            assert st["n_kept"] == int(okept.sum()) and st["n_umis"] == len(keys)
+            assert (np.unpackbits(t_bits.cpu().numpy(), bitorder="little")[:len(keys)] == okept).all()
+        # two begins in a row: the first ends by itself; then a plain call; then the pending end
+        keys, nm, fr, off = small
+        t_keys = torch.from_numpy(keys.view(np.int64)).to(dev)
+        t_fr = torch.from_numpy(fr).to(dev)
+        t_kept = torch.zeros(len(keys), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            c.dedup_batch_device_begin(t_keys.data_ptr(), 0, t_fr.data_ptr(), off, 12, t_kept.data_ptr(), 0, k=1, stream=stream)
+        st_plain = c.dedup_batch_device(t_keys.data_ptr(), 0, t_fr.data_ptr(), off, 12, t_kept.data_ptr(), 0, k=1, stream=stream)
+        okept, _, _ = orc.dedup_batch(keys, None, fr, off, 12, 1)
+        assert st_plain["n_kept"] == int(okept.sum()) and (t_kept.cpu().numpy() == okept).all()
+        assert c.dedup_batch_end()["n_kept"] == int(okept.sum())  # (the plain call let the pending one end; its result waited)
+        with pytest.raises(umi.UmiHipError):
+            c.dedup_batch_end()  # (handed out: nothing is out now)
+        # a contract violation (rank order) is reported by end
+        bad = fr.copy()
+        first = int(off[0]); n0 = int(off[1] - off[0])
+        if n0 >= 2:
+            bad[first], bad[first + 1] = 1, 5
+            t_bad = torch.from_numpy(bad).to(dev)
+            c.dedup_batch_device_begin(t_keys.data_ptr(), 0, t_bad.data_ptr(), off, 12, t_kept.data_ptr(), 0, k=1, stream=stream)
+            with pytest.raises(umi.UmiHipError):
+                c.dedup_batch_end()
+            # ... and by begin where the call runs to its end there
+            kd, _, fd, od = deep
+            fd = fd.copy()
+            fd[int(od[-2])], fd[int(od[-2]) + 1] = 1, 7
+            with pytest.raises(umi.UmiHipError):
+                c.dedup_batch_device_begin(torch.from_numpy(kd.view(np.int64)).to(dev).data_ptr(), 0,
+                                           torch.from_numpy(fd).to(dev).data_ptr(), od, 12,
+                                           torch.zeros(len(kd), dtype=torch.uint8, device=dev).data_ptr(), 0, k=1, stream=stream)
+    finally:
+        c.close()
+
+
 def test_contract_violations_are_reported(ctx):
     import umi_collapse_rs_amd as umi
     from umi_collapse_rs_amd import _lib

@@ -31,9 +31,7 @@ for c in ("3", "4", "5", "2m", "wide24"):
         print("config %s: %.4f ms/step, %.3e reads/s, %s %.1f us, frac %.4f" % (
             c, j["ms_per_step"], j["reads_per_s"], j["roofline"]["kernel"], j["roofline"]["kernel_us"], j["roofline"]["frac"]))
 shutil.copy(os.path.join(SRC, "end_to_end_split.txt"), os.path.join(DST, "r03_end_to_end_split.txt"))
-# (the library prints "of which GPU %.3f ms" from the per-phase events, which these calls do not record)
-keep = [l.replace(" of which GPU 0.000 ms", "") for l in open(os.path.join(SRC, "fullscale.txt"))
-        if "entries in" in l or l.startswith("    ") or "passed" in l]
+keep = [l for l in open(os.path.join(SRC, "fullscale.txt")) if "entries in" in l or l.startswith("    ") or "passed" in l]
 open(os.path.join(DST, "r03_fullscale_configs_4_5.txt"), "w").write(
     "tests/test_gpu_fullscale.py -s on the 1-GPU box: BASELINE configs 4 and 5 at full size through an 8-worker\n"
     "context (umi.Context([0] * 8)); per worker: gather into pinned memory | the call | scatter back\n\n" + "".join(keep))

@@ -74,6 +74,10 @@ SIGNATURES = {
                                                C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(Stats)]),
+    "umi_dedup_batch_device_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u64p, C.c_void_p,
+                                               C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int,
+                                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "umi_dedup_batch_end": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "umi_pack_mask_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "umi_dedup_batch_device_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_void_p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int,

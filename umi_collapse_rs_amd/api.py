@@ -191,6 +191,23 @@ class Context:
         return st.as_dict()
 
 
+    def dedup_batch_device_begin(self, d_keys, d_nmask, d_freq, bucket_off, umi_len, d_kept, d_root=0,
+                                 k=1, percentage=0.5, algo=UMI_ALGO_DIRECTIONAL, adj_max_freq=0,
+                                 stream=0, d_bucket_off=0):
+        """umi_dedup_batch_device_begin: the device-pointer call enqueued on `stream`; where every position is
+        the fused kernel's it returns without waiting (d_kept / d_root final in stream order), else it
+        runs to its end.  dedup_batch_end() waits and returns the stats."""
+        bucket_off = np.ascontiguousarray(bucket_off, dtype=np.uint64)
+        check(load().umi_dedup_batch_device_begin(self._h, d_keys, d_nmask or None, d_freq,
+                                                  ptr(bucket_off, C.c_uint64), d_bucket_off or None,
+                                                  len(bucket_off) - 1, umi_len, k, percentage, algo,
+                                                  adj_max_freq, d_kept, d_root or None, stream or None))
+
+    def dedup_batch_end(self):
+        st = Stats()
+        check(load().umi_dedup_batch_end(self._h, C.byref(st)))
+        return st.as_dict()
+
     def dedup_batch_device_multi(self, shards, umi_len, slice_bytes, k=1, percentage=0.5, algo=UMI_ALGO_DIRECTIONAL,
                                  adj_max_freq=0, gather=True):
         """umi_dedup_batch_device_multi on a multi-device context: shards = one dict per device with the

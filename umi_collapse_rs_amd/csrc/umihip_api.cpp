@@ -233,6 +233,15 @@ struct umi_ctx {
     unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES), then, in a line of
                                               // its own, the sequence number of the last copy that has arrived
     unsigned long long ctrl_seq = 0;          // ... and of the last copy asked for
+    // umi_dedup_batch_device_begin / umi_dedup_batch_end: a call whose work is all on the stream and whose
+    // control block has not been looked at yet (deferred), or whose result waits to be handed out
+    struct PendingCall {
+        bool deferred = false, have_result = false;
+        unsigned long long seq = 0;
+        hipStream_t stream = nullptr;
+        int rc = UMI_OK;
+        umi_stats st;
+    } pending;
     bool spin_wait = true;                    // watch that number instead of hipStreamSynchronize (option "spin_wait")
     unsigned long long *h_seq() const { return h_counters + CTRL_BYTES / sizeof(unsigned long long); }
     uint32_t *h_changed() const { return (uint32_t *)(h_counters + CNT_COUNT); }
@@ -369,6 +378,7 @@ class Pipeline {
     // on all words; the fused kernel slices all words' bases; buckets in between go to the exact
     // all-pairs kernel of umihip_wide.hip.
     void use_wide_keys(int words) { n_words = words; }
+    void allow_deferred_end() { may_defer = true; }
 
   private:
     umi_ctx *ctx;
@@ -397,6 +407,7 @@ class Pipeline {
                                   // after the pair kernels (multi-GPU split of one call's pairs)
     uint64_t task_counter = 0;    // running index over all tile tasks, for that split
     bool prune = false, drained = false, fused_ran = false, seg_timed = false;
+    bool may_defer = false; // umi_dedup_batch_device_begin: the end of the call may be left on the stream
     size_t zero_behind_control = 0; // bytes of the segment index's counters that sit behind the control block
     uint32_t priv_blocks_for_collapse = 0; // blocks of the segment index's pair kernel whose private edge slots the
                                            // collapse's flatten launch appends to the list (0: appended already)
@@ -499,6 +510,18 @@ class Pipeline {
         v.resize(w);
     }
 
+    // the tail of a call that may be left on the stream: the control copy with its sequence number, no wait
+    // (umi_dedup_batch_device_begin; the caller's umi_dedup_batch_end looks)
+    int defer_control()
+    {
+        ctx->pending.seq = ++ctx->ctrl_seq;
+        ctx->pending.stream = s;
+        HIP_TRY(launch_control_to_host(d_cnt, ctx->h_counters, CTRL_BYTES, s, ctx->h_seq(), ctx->pending.seq));
+        ctx->pending.st = st;
+        ctx->pending.deferred = true;
+        drained = true; // (run() does not wait either)
+        return UMI_OK;
+    }
     int read_control()
     {
         if (ctx->spin_wait && !prof) { // (the phase profile reads events afterwards: they want the runtime's wait)
@@ -1147,6 +1170,12 @@ class Pipeline {
                 HIP_TRY(hipEventRecord(ctx->ev[3], s));
                 HIP_TRY(hipEventRecord(ctx->ev[4], s));
             }
+            // (a call without pair work -- every position the fused kernel's -- has nothing left to decide
+            // on the host: its end may be left to the caller)
+            if (may_defer && !have_pairs && !prof && ctx->spin_wait) {
+                st.n_pairs_evaluated = pl.n_pairs_eval;
+                return defer_control();
+            }
             if ((rc = read_control())) return rc;
             note_pair_counters();
             if (pl.seg_parts && seg_tasks_made > seg.task_cap)
@@ -1356,17 +1385,63 @@ class EdgeCollapse {
     }
 };
 
+void settle(umi_ctx *ctx);
 int run_pipeline(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask,
                  const int32_t *d_freq, const uint64_t *bucket_off, uint64_t n_buckets, uint32_t n,
                  int umi_len, int k, float percentage, int mode, int32_t adj_max_freq,
                  uint8_t *d_kept, uint32_t *d_root, hipStream_t s, umi_stats *stats,
-                 const uint64_t *d_bucket_off = nullptr, int n_words = 1)
+                 const uint64_t *d_bucket_off = nullptr, int n_words = 1, bool may_defer = false)
 {
+    settle(ctx); // (a deferred call owns the workspace until its end has been seen)
     Pipeline p(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, n, umi_len, k, percentage, mode, adj_max_freq,
                d_kept, d_root, s);
     p.use_device_table(d_bucket_off);
     p.use_wide_keys(n_words);
+    if (may_defer) p.allow_deferred_end();
     return p.run(stats);
+}
+
+// the end of a deferred call: its control block has arrived (watched for, as in Pipeline::read_control),
+// the contract verdict, the counts
+int finish_pending(umi_ctx *ctx, umi_stats *stats)
+{
+    umi_ctx::PendingCall &pc = ctx->pending;
+    if (pc.deferred) {
+        pc.deferred = false;
+        HIP_TRY(hipSetDevice(ctx->device));
+        const auto t0 = std::chrono::steady_clock::now();
+        bool there = false;
+        for (unsigned spins = 0; !there; spins++) {
+            there = __atomic_load_n(ctx->h_seq(), __ATOMIC_ACQUIRE) == pc.seq;
+            if (!there && (spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        if (!there) HIP_TRY(hipStreamSynchronize(pc.stream));
+        const unsigned long long bad =
+            ctx->h_counters[CNT_ERROR] + (ctx->h_counters[CNT_RISES] - ctx->h_counters[CNT_START_RISES]);
+        pc.rc = UMI_OK;
+        if (bad)
+            pc.rc = fail(UMI_ERR_ORDER,
+                         "%llu entries break the input contract (freq < 1, not in freq-descending rank "
+                         "order inside a bucket, or an N base without nmask)",
+                         bad);
+        pc.st.n_candidates = ctx->h_counters[CNT_CANDIDATES];
+        pc.st.n_kept = ctx->h_counters[CNT_KEPT] + ctx->h_counters[CNT_KEPT_FUSED];
+        pc.have_result = true;
+    }
+    if (!pc.have_result) return fail(UMI_ERR_ARG, "umi_dedup_batch_end without umi_dedup_batch_device_begin");
+    pc.have_result = false;
+    if (pc.rc == UMI_OK && stats) *stats = pc.st;
+    return pc.rc;
+}
+// every other entry point that touches the context's workspace first lets a deferred call end (its
+// result keeps waiting for umi_dedup_batch_end)
+void settle(umi_ctx *ctx)
+{
+    if (ctx && ctx->pending.deferred) {
+        umi_stats st;
+        (void)finish_pending(ctx, &st);
+        ctx->pending.have_result = true;
+    }
 }
 
 
@@ -1470,8 +1545,8 @@ void run_shard(umi_ctx *sub, const std::vector<uint64_t> &mine, const uint64_t *
     }
     if (timing)
         fprintf(stderr, "umihip multi: device %d: %llu entries in %zu buckets: host gather %.4f s, call (H2D + GPU + D2H) "
-                        "%.4f s of which GPU %.3f ms, host scatter %.4f s\n",
-                sub->device, (unsigned long long)n_local, mine.size(), t1 - t0, t2 - t1, st.ms_total, now() - t2);
+                        "%.4f s, host scatter %.4f s\n",
+                sub->device, (unsigned long long)n_local, mine.size(), t1 - t0, t2 - t1, now() - t2);
 }
 
 // the multi-device split of a call whose work is one giant bucket
@@ -1705,6 +1780,7 @@ int umi_ctx_create(int device_id, umi_ctx **out)
 void umi_ctx_destroy(umi_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->subs.empty()) settle(ctx);
     if (!ctx->subs.empty()) { // a multi-device context: nothing of its own on a device
         for (ncclComm_t c : ctx->comms)
             if (c && ctx->rccl.CommDestroy) (void)ctx->rccl.CommDestroy(c);
@@ -2023,6 +2099,7 @@ int umi_stage_reads_wide_device(umi_ctx *ctx, const uint64_t *d_align_key, int a
     if (merge != 0 && merge != 1) return fail(UMI_ERR_ARG, "merge must be 0 (any) or 1 (highest score, first on ties)");
     if (n_reads >= (1ull << 30)) return fail(UMI_ERR_ARG, "%llu reads exceed the 30-bit index space of one staging call", (unsigned long long)n_reads);
     HIP_TRY(hipSetDevice(ctx->device));
+    settle(ctx);
     int rc;
     if ((rc = ctx->stage_ws.reserve(stage_workspace_bytes((uint32_t)n_reads, n_words)))) return rc;
     hipStream_t s = (hipStream_t)hip_stream; // (NULL = the default stream, as in every device-pointer call)
@@ -2157,6 +2234,51 @@ int umi_dedup_batch_device_table(umi_ctx *ctx, const uint64_t *d_keys, const uin
                         k, percentage,
                         algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY,
                         adj_max_freq, d_kept, d_root, (hipStream_t)hip_stream, stats, d_bucket_off);
+}
+
+int umi_dedup_batch_device_begin(umi_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_nmask, const int32_t *d_freq,
+                                 const uint64_t *bucket_off, const uint64_t *d_bucket_off, uint64_t n_buckets,
+                                 int umi_len, int k, float percentage, int algo, int32_t adj_max_freq, uint8_t *d_kept,
+                                 uint32_t *d_root, void *hip_stream)
+{
+    if (ctx && !ctx->subs.empty()) {
+        if (ctx->subs.size() > 1)
+            return fail(UMI_ERR_ARG, "device pointers belong to one device: use a single-device context");
+        ctx = ctx->subs[0];
+    }
+    uint64_t n = 0;
+    int rc = check_common(ctx, bucket_off, n_buckets, umi_len, k, algo, &n);
+    if (rc) return rc;
+    if (n && (!d_keys || !d_freq || !d_kept)) return fail(UMI_ERR_ARG, "keys/freq/kept is NULL");
+    settle(ctx);
+    umi_ctx::PendingCall &pc = ctx->pending;
+    pc.have_result = false;
+    memset(&pc.st, 0, sizeof(pc.st));
+    if (n == 0) {
+        pc.st.n_buckets = n_buckets;
+        pc.rc = UMI_OK;
+        pc.have_result = true;
+        return UMI_OK;
+    }
+    umi_stats st;
+    memset(&st, 0, sizeof(st));
+    rc = run_pipeline(ctx, d_keys, d_nmask, d_freq, bucket_off, n_buckets, (uint32_t)n, umi_len, k, percentage,
+                      algo == UMI_ALGO_DIRECTIONAL ? MODE_DIRECTIONAL : MODE_ADJACENCY, adj_max_freq, d_kept, d_root,
+                      (hipStream_t)hip_stream, &st, d_bucket_off, 1, true);
+    if (rc) return rc; // (nothing is pending: the call failed where a plain call would have)
+    if (!pc.deferred) { // the call had decisions to take on the host and has run to its end
+        pc.st = st;
+        pc.rc = UMI_OK;
+        pc.have_result = true;
+    }
+    return UMI_OK;
+}
+
+int umi_dedup_batch_end(umi_ctx *ctx, umi_stats *stats)
+{
+    if (!ctx) return fail(UMI_ERR_ARG, "ctx is NULL");
+    if (!ctx->subs.empty()) ctx = ctx->subs[0];
+    return finish_pending(ctx, stats);
 }
 
 int umi_dedup_batch_device_multi(umi_ctx *ctx, const uint64_t *const *d_keys, const uint64_t *const *d_nmask,
@@ -2310,6 +2432,7 @@ int umi_collapse_edges_device(umi_ctx *ctx, uint64_t n, const uint64_t *d_edges,
     if (algo != UMI_ALGO_DIRECTIONAL && algo != UMI_ALGO_ADJACENCY)
         return fail(UMI_ERR_ARG, "unknown algo %d", algo);
     if (n >= 0x7FFFFFF0ull || n_edges >= 0x7FFFFFF0ull) return fail(UMI_ERR_ARG, "too many entries/edges");
+    settle(ctx);
     if (n == 0) return UMI_OK;
     if (!d_kept || (n_edges && !d_edges)) return fail(UMI_ERR_ARG, "kept/edges is NULL");
     return EdgeCollapse(ctx, (uint32_t)n, (const uint2 *)d_edges, (uint32_t)n_edges,

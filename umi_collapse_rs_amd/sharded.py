@@ -129,17 +129,24 @@ class ShardedDedup:
             stream = torch.cuda.current_stream().cuda_stream
             p = self.params
             if n:
-                self.ctx.dedup_batch_device(sh["d_keys"].data_ptr(),
-                                            0 if sh["d_nmask"] is None else sh["d_nmask"].data_ptr(),
-                                            sh["d_freq"].data_ptr(), sh["loff"], p["umi_len"], sh["d_kept"].data_ptr(), 0,
-                                            k=p["k"], percentage=p["percentage"], algo=p["algo"],
-                                            adj_max_freq=p["adj_max_freq"], stream=stream)
+                # the call in two halves (umi_dedup_batch_device_begin / _end): packing and gathering are
+                # enqueued behind the call's kernels while those run
+                self.ctx.dedup_batch_device_begin(sh["d_keys"].data_ptr(),
+                                                  0 if sh["d_nmask"] is None else sh["d_nmask"].data_ptr(),
+                                                  sh["d_freq"].data_ptr(), sh["loff"], p["umi_len"], sh["d_kept"].data_ptr(), 0,
+                                                  k=p["k"], percentage=p["percentage"], algo=p["algo"],
+                                                  adj_max_freq=p["adj_max_freq"], stream=stream)
                 self.ctx.pack_mask_device(sh["d_kept"].data_ptr(), n, sh["d_bits"].data_ptr(), stream=stream)
             mx = sh["d_bits"].numel()
             if self.dist.get_backend() == "nccl":  # RCCL over xGMI: device to device
-                self.dist.all_gather_into_tensor(sh["d_all"], sh["d_bits"])
+                work = self.dist.all_gather_into_tensor(sh["d_all"], sh["d_bits"], async_op=True)
+                if n:
+                    self.ctx.dedup_batch_end()  # (a contract violation of this rank's shard surfaces here)
+                work.wait()
                 out = sh["d_all"]
             else:  # a rehearsal over gloo (several ranks on one GPU): the packed slice via the host
+                if n:
+                    self.ctx.dedup_batch_end()
                 out = torch.empty(mx * self.world, dtype=torch.uint8)
                 self.dist.all_gather_into_tensor(out, sh["d_bits"].cpu())
             return [out[r * mx: r * mx + counts[r]] for r in range(self.world)]
