@@ -198,3 +198,28 @@ def test_device_form_with_text_off_the_word_boundary_and_any_key_width(ctx, L, n
     assert (d_freq[:ne].cpu().numpy() == want["freq"]).all()
     assert (outs[2][:ne].cpu().numpy().view(np.uint64) == want["rep"]).all()
     assert (d_off[:nb + 1].cpu().numpy().view(np.uint64) == want["bucket_off"]).all()
+
+
+def test_local_order_with_64_bit_order_keys():
+    """Positions of up to 1,024 entries are ordered by a wave each (no sort): with 32-bit order keys where the
+    freq field and the read index fit them together, else with 64-bit ones -- forced here through the
+    environment (it takes 2^24 reads otherwise), in a process of its own: the library reads it once."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle as orc, umi_collapse_rs_amd as umi\n"
+        "import test_gpu_stage as t\n"
+        "rng = np.random.default_rng(77)\n"
+        "c = umi.Context(0)\n"
+        "for n_reads, n_pos, L, n_mol, merge, srt in ((30000, 400, 12, 9, 1, False), (5000, 3, 10, 300, 0, True), (70, 70, 7, 1, 1, True)):\n"
+        "    pos, u, score = t.make_reads(rng, n_reads, n_pos, L, n_mol, n_frac=0.003, sorted_file=srt)\n"
+        "    got = c.stage_reads(pos.astype(np.uint64), u, score, L, merge=merge)\n"
+        "    t.compare(got, orc.stage_reads(t.dense_ids(pos), u, score, L, merge))\n"
+        "c.close(); print('ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, UMIHIP_STAGE_WIDE_ORDER="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

@@ -25,6 +25,7 @@
 // Integer / byte work, HBM streams; no MFMA.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "umihip_internal.h"
@@ -39,7 +40,7 @@ inline uint32_t grid_for(uint64_t n, int block = 256, uint32_t cap = 4096)
     return (uint32_t)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-enum StageCounter : int { SC_BAD = 0, SC_ENTRIES = 1, SC_BUCKETS = 2, SC_FMAX = 3, SC_COUNT = 4 };
+enum StageCounter : int { SC_BAD = 0, SC_ENTRIES = 1, SC_BUCKETS = 2, SC_FMAX = 3, SC_PMAX = 4, SC_COUNT = 5 };
 
 // ---- 1. encode ------------------------------------------------------------------------------------
 // Four bases at a time: the ASCII codes of A C G T N differ in bits 1..3 (A 000, C 001, T 010, G 011,
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void stage_head_apply_kernel(SortedReads s, co
                                                                uint32_t *__restrict__ ent_bseq,
                                                                uint64_t *__restrict__ ent_key,
                                                                uint32_t *__restrict__ bfirst, uint32_t *__restrict__ numbers,
+                                                               uint32_t *__restrict__ pos_start,
                                                                unsigned long long *__restrict__ counters)
 {
     __shared__ unsigned long long cell[HT_CELLS];
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) void stage_head_apply_kernel(SortedReads s, co
                 head_pos[e] = i;
                 ent_first[e] = rd;
                 ent_bseq[e] = b;
+                if ((pb[r] >> lane) & 1ull) pos_start[b] = e; // (a position's first read is an entry's first)
                 if (s.composed) { // (W == 1: the UMI key is the low part of the sorted composed key)
                     ent_key[e] = s.umi_bits >= 64 ? s.composed[i] : s.composed[i] & ((1ull << s.umi_bits) - 1ull); // (still packed)
                 } else {
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256) void stage_head_apply_kernel(SortedReads s, co
             }
             if (i == s.n - 1) {
                 head_pos[e_incl] = s.n;
+                pos_start[b_incl] = e_incl;
                 counters[SC_ENTRIES] = e_incl;
                 counters[SC_BUCKETS] = b_incl;
             }
@@ -363,24 +367,36 @@ __global__ __launch_bounds__(256) void stage_head_apply_kernel(SortedReads s, co
     }
 }
 
-// the largest freq of any entry (the width of the freq field of the final sort key)
-__global__ __launch_bounds__(256) void stage_fmax_kernel(const uint32_t *__restrict__ head_pos,
-                                                         unsigned long long *__restrict__ counters)
+// block maximum of m to counters[which]: one atomic per block, and a look first
+__device__ __forceinline__ void block_max_to(uint32_t m, unsigned long long *word)
 {
-    const uint32_t n_entries = (uint32_t)counters[SC_ENTRIES];
-    uint32_t m = 0;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x)
-        m = max(m, head_pos[e + 1] - head_pos[e]);
-    // one atomic per block, and a look first: one word takes ~90 accesses per microsecond
     __shared__ uint32_t wmax[4];
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
+    __syncthreads(); // (wmax may be in use by the call before)
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-        if (m && __hip_atomic_load(&counters[SC_FMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)m)
-            atomicMax(&counters[SC_FMAX], (unsigned long long)m);
+        if (m && __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)m)
+            atomicMax(word, (unsigned long long)m);
     }
+}
+
+// the largest freq of any entry (the width of the freq field of the final sort key) and the most
+// entries of any position (whether a wave can order a position by itself)
+__global__ __launch_bounds__(256) void stage_fmax_kernel(const uint32_t *__restrict__ head_pos,
+                                                         const uint32_t *__restrict__ pos_start,
+                                                         unsigned long long *__restrict__ counters)
+{
+    const uint32_t n_entries = (uint32_t)counters[SC_ENTRIES], n_buckets = (uint32_t)counters[SC_BUCKETS];
+    uint32_t pm = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += gridDim.x * blockDim.x)
+        pm = max(pm, pos_start[b + 1] - pos_start[b]);
+    block_max_to(pm, &counters[SC_PMAX]);
+    uint32_t m = 0;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x)
+        m = max(m, head_pos[e + 1] - head_pos[e]);
+    block_max_to(m, &counters[SC_FMAX]);
 }
 
 // The maximum of v over the lanes of a wave that share a run of equal ids, at the last lane of each
@@ -636,6 +652,121 @@ __global__ __launch_bounds__(256) void stage_emit_kernel(const uint32_t *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) bucket_off[n_buckets] = n_entries;
 }
 
+// ---- 3'. the canonical order where no position has more than LOCAL_MAX entries: no sort --------------
+// A position's entries are neighbours already (the reads were sorted by alignment key); what is left is
+// their order among themselves -- freq descending, ties by first appearance -- and where the position
+// starts in the output: the sizes of the positions in rank order, scanned.  A wave takes a position:
+// its (max freq - freq, first read) keys go to LDS, every lane counts the keys below its own (all
+// pairs: a position of 60 entries is 60 broadcast reads), and writes its entry where it belongs.  At
+// 10^7 reads in 10^5 positions this replaces the order kernel, three radix passes and the gather.
+constexpr uint32_t LOCAL_MAX = 1024;
+__global__ __launch_bounds__(256) void stage_rank_sizes_kernel(const uint32_t *__restrict__ pos_start,
+                                                               const uint32_t *__restrict__ brank_of, uint32_t n_buckets,
+                                                               uint64_t *__restrict__ size_by_rank)
+{
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += gridDim.x * blockDim.x)
+        size_by_rank[brank_of[b]] = pos_start[b + 1] - pos_start[b];
+}
+
+// OrdT: uint32_t where (max freq - freq) and the first read's index fit 32 bits together (first_bits for
+// the index), else uint64_t (the index in the low word)
+template <int W, typename OrdT>
+__global__ __launch_bounds__(256) void stage_emit_local_kernel(const uint32_t *__restrict__ pos_start,
+                                                               const uint32_t *__restrict__ brank_of,
+                                                               const uint64_t *__restrict__ end_by_rank, // inclusive scan of the sizes
+                                                               uint32_t n_entries, uint32_t n_buckets, int merge, int umi_len,
+                                                               uint32_t fmax, int first_bits, Pack5 p5, int packed,
+                                                               const uint64_t *__restrict__ ent_key,
+                                                               const uint32_t *__restrict__ ent_first,
+                                                               const uint32_t *__restrict__ head_pos,
+                                                               const unsigned long long *__restrict__ best,
+                                                               uint64_t *__restrict__ keys, uint64_t *__restrict__ nmask,
+                                                               int32_t *__restrict__ freq, uint64_t *__restrict__ rep,
+                                                               uint64_t *__restrict__ bucket_off)
+{
+    constexpr bool NARROW = sizeof(OrdT) == 4;
+    constexpr uint32_t PER_READ = 16 / sizeof(OrdT); // keys per 16-byte LDS read
+    __shared__ __attribute__((aligned(16))) OrdT order_key[4][LOCAL_MAX + PER_READ];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    OrdT *mine = order_key[wave];
+    const uint32_t n_waves = gridDim.x * 4;
+    const uint32_t first_mask = NARROW ? (first_bits >= 32 ? 0xFFFFFFFFu : (1u << first_bits) - 1u) : 0xFFFFFFFFu;
+    for (uint32_t b = blockIdx.x * 4 + wave; b < n_buckets; b += n_waves) {
+        const uint32_t s0 = pos_start[b], cnt = pos_start[b + 1] - s0, br = brank_of[b];
+        const uint64_t first_out = end_by_rank[br] - cnt;
+        if (lane == 0) bucket_off[br] = first_out;
+        const uint32_t padded = (cnt + PER_READ - 1) / PER_READ * PER_READ;
+        for (uint32_t i = lane; i < padded; i += 64) {
+            const uint32_t e = s0 + i;
+            OrdT v = (OrdT)~(OrdT)0; // (padding: below no key)
+            if (i < cnt) {
+                const uint32_t down = fmax - (head_pos[e + 1] - head_pos[e]);
+                v = NARROW ? (OrdT)((down << first_bits) | ent_first[e]) : (OrdT)(((unsigned long long)down << 32) | ent_first[e]);
+            }
+            mine[i] = v;
+        }
+        __builtin_amdgcn_wave_barrier(); // (a wave's LDS accesses complete in order)
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < cnt;
+            const OrdT k = valid ? mine[i] : (OrdT)0;
+            uint32_t below = 0;
+            for (uint32_t j = 0; j < padded; j += PER_READ) { // (one address for the wave: a broadcast of 16 bytes)
+                if (NARROW) {
+                    const uint4 q = *(const uint4 *)&mine[j];
+                    below += (q.x < k ? 1u : 0u) + (q.y < k ? 1u : 0u) + (q.z < k ? 1u : 0u) + (q.w < k ? 1u : 0u);
+                } else {
+                    const ulonglong2 q = *(const ulonglong2 *)&mine[j];
+                    below += (q.x < k ? 1u : 0u) + (q.y < k ? 1u : 0u);
+                }
+            }
+            if (!valid) continue;
+            const uint32_t e = s0 + i;
+            const uint64_t out = first_out + below;
+            uint64_t key[W];
+            if (packed) {
+                key[0] = unpack5(ent_key[e], p5);
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; w++) key[w] = ent_key[(size_t)e * W + w];
+            }
+#pragma unroll
+            for (int w = 0; w < W; w++) keys[out * W + w] = key[w];
+            if (nmask) {
+                if (W == 1) {
+                    nmask[out] = nmask_of(key[0]);
+                } else {
+                    uint64_t m[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++) m[w] = 0;
+                    for (int bb = 0; bb < umi_len; bb++) {
+                        const int bit = 3 * bb, w = bit >> 6, sh = bit & 63;
+                        uint64_t c = 0;
+#pragma unroll
+                        for (int q = 0; q < W; q++) {
+                            if (q == w) c |= key[q] >> sh;
+                            if (q == w + 1 && sh > 61) c |= key[q] << (64 - sh);
+                        }
+                        if ((c & 7ull) == 4ull) {
+#pragma unroll
+                            for (int q = 0; q < W; q++) {
+                                if (q == w) m[q] |= 7ull << sh;
+                                if (q == w + 1 && sh > 61) m[q] |= 7ull >> (64 - sh);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < W; w++) nmask[out * W + w] = m[w];
+                }
+            }
+            freq[out] = (int32_t)(fmax - (uint32_t)(NARROW ? (uint64_t)k >> first_bits : (uint64_t)k >> 32));
+            rep[out] = merge ? (uint64_t)(0xFFFFFFFFu - (uint32_t)best[e]) : (uint64_t)((uint32_t)k & first_mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bucket_off[n_buckets] = n_entries;
+}
+
 inline int bits_for(uint64_t v)
 {
     int b = 1;
@@ -657,7 +788,7 @@ struct Carver {
 struct StageBufs {
     uint64_t *k3, *keyA, *keyB, *ent_key, *file_flags;
     unsigned long long *best, *tile_sums;
-    uint32_t *idxA, *idxB, *ent_first, *ent_bseq, *head_pos, *bfirst, *numbers, *brank_of;
+    uint32_t *idxA, *idxB, *ent_first, *ent_bseq, *head_pos, *bfirst, *numbers, *brank_of, *pos_start;
     EntryRec *rec;
     RankRec *rank_rec;
     unsigned long long *counters;
@@ -687,8 +818,9 @@ StageBufs carve(void *ws, uint32_t n, int n_words)
     b.bfirst = c.take<uint32_t>(m);
     b.numbers = c.take<uint32_t>(m);
     b.brank_of = c.take<uint32_t>(m);
+    b.pos_start = c.take<uint32_t>(m);
     b.counters = c.take<unsigned long long>(SC_COUNT);
-    b.tmp_bytes = radix_sort_temp_bytes(n) + 256;
+    b.tmp_bytes = std::max(radix_sort_temp_bytes(n), scan_temp_bytes(n)) + 256;
     b.tmp = c.take<char>(b.tmp_bytes);
     b.total = c.off;
     return b;
@@ -757,14 +889,14 @@ int stage_impl(void *workspace, const uint64_t *d_align, int align_bits, const u
     stage_head_sums_kernel<W><<<tiles, 256, 0, s>>>(sr, b.tile_sums);
     STAGE_TRY(scan_spine_u64(b.tile_sums, tiles, s));
     stage_head_apply_kernel<W><<<tiles, 256, 0, s>>>(sr, b.tile_sums, b.head_pos, b.ent_first, b.ent_bseq, b.ent_key, b.bfirst,
-                                                    use_score ? b.numbers : nullptr, b.counters);
-    stage_fmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, s>>>(b.head_pos, b.counters);
+                                                    use_score ? b.numbers : nullptr, b.pos_start, b.counters);
+    stage_fmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, s>>>(b.head_pos, b.pos_start, b.counters);
     // the host needs the counts to size what follows (and the verdict on the characters)
     STAGE_TRY(hipMemcpyAsync(h_pinned4, b.counters, SC_COUNT * 8, hipMemcpyDeviceToHost, s));
     STAGE_TRY(hipStreamSynchronize(s));
     if (h_pinned4[SC_BAD]) return 1;
     const uint32_t E = (uint32_t)h_pinned4[SC_ENTRIES], B = (uint32_t)h_pinned4[SC_BUCKETS];
-    const uint32_t fmax = (uint32_t)h_pinned4[SC_FMAX];
+    const uint32_t fmax = (uint32_t)h_pinned4[SC_FMAX], pmax = (uint32_t)h_pinned4[SC_PMAX];
     if (use_score) {
         STAGE_TRY(hipMemsetAsync(b.best, 0, (size_t)E * 8, s));
         stage_best_kernel<<<grid_for(n), 256, 0, s>>>(b.numbers, va, d_score, n, b.best);
@@ -776,6 +908,27 @@ int stage_impl(void *workspace, const uint64_t *d_align, int align_bits, const u
     stage_rank_sums_kernel<<<n_blocks, 256, 0, s>>>(b.file_flags, n_groups, b.rank_rec, b.tile_sums);
     STAGE_TRY(scan_spine_u64(b.tile_sums, n_blocks, s));
     stage_position_rank_kernel<<<grid_for(B), 256, 0, s>>>(b.bfirst, B, b.rank_rec, b.tile_sums, b.brank_of);
+    if (pmax <= LOCAL_MAX) { // ---- 3'. every position fits a wave's LDS: ordered where it lies, no sort
+        uint64_t *size_by_rank = b.keyA, *end_by_rank = b.keyB; // (the read sort's buffers are free)
+        stage_rank_sizes_kernel<<<grid_for(B), 256, 0, s>>>(b.pos_start, b.brank_of, B, size_by_rank);
+        STAGE_TRY(scan_inclusive_u64(size_by_rank, end_by_rank, B, b.tmp, b.tmp_bytes, s));
+        const int first_bits = bits_for(n - 1);
+        // (UMIHIP_STAGE_WIDE_ORDER: the tests' way to the 64-bit form, which otherwise needs 2^24 reads and a freq to match)
+        static const bool force_wide = getenv("UMIHIP_STAGE_WIDE_ORDER") != nullptr;
+        if (first_bits + bits_for(fmax) <= 32 && !force_wide)
+            stage_emit_local_kernel<W, uint32_t><<<grid_for((uint64_t)B, 4, 8192), 256, 0, s>>>(
+                b.pos_start, b.brank_of, end_by_rank, E, B, use_score ? 1 : 0, umi_len, fmax, first_bits, p5, one_key ? 1 : 0,
+                b.ent_key, b.ent_first, b.head_pos, b.best, d_keys, d_nmask, d_freq, d_rep, d_bucket_off);
+        else
+            stage_emit_local_kernel<W, uint64_t><<<grid_for((uint64_t)B, 4, 4096), 256, 0, s>>>(
+                b.pos_start, b.brank_of, end_by_rank, E, B, use_score ? 1 : 0, umi_len, fmax, 32, p5, one_key ? 1 : 0,
+                b.ent_key, b.ent_first, b.head_pos, b.best, d_keys, d_nmask, d_freq, d_rep, d_bucket_off);
+        STAGE_TRY(hipGetLastError());
+        STAGE_TRY(hipStreamSynchronize(s));
+        *n_entries_out = E;
+        *n_buckets_out = B;
+        return 0;
+    }
     // ... and one stable sort of the entries, taken in that order, by (position rank, max freq - freq).
     // (Everything of the read sort but its order, va, is free by now -- and va's twin and the entry
     // numbers too, in stream order.)
