@@ -51,10 +51,18 @@ PROFILE_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
 KERNEL_NAMES = {0: None, 1: "small_bucket_kernel", 2: "seg_pair_kernel"}
 
 
+def stamped_sources():
+    """The sources whose kernels the counters of profiles/r03_counters.json belong to: the hot path's.  The
+    read staging (umihip_stage.hip, umihip_radix.hip) is measured by itself (tools/stage_prof.sh,
+    profiles/r03_staging_kernel_split.txt) and not part of the stamp."""
+    return [f for f in sorted(glob.glob(os.path.join(ROOT, "umi_collapse_rs_amd", "csrc", "*")))
+            if os.path.basename(f) not in ("umihip_stage.hip", "umihip_radix.hip")]
+
+
 def source_sha256():
-    """sha256 over the kernel and host sources of the library (sorted file names, contents)."""
+    """sha256 over the kernel and host sources of the hot path (sorted file names, contents)."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "umi_collapse_rs_amd", "csrc", "*"))):
+    for f in stamped_sources():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

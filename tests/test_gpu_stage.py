@@ -200,6 +200,16 @@ def test_device_form_with_text_off_the_word_boundary_and_any_key_width(ctx, L, n
     assert (d_off[:nb + 1].cpu().numpy().view(np.uint64) == want["bucket_off"]).all()
 
 
+def test_many_tiny_positions_and_few_deep_ones_take_the_sort(ctx):
+    """Both ways to the canonical order on one context: positions of some tens of entries are ordered by a wave
+    each; a file of (nearly) singleton positions, and one with a position beyond 1,024 entries, go through the
+    order sort."""
+    rng = np.random.default_rng(99)
+    for n_reads, n_pos, n_mol in ((40000, 500, 30), (40000, 30000, 1), (40000, 4, 4000), (40000, 500, 30)):
+        pos, umi, score = make_reads(rng, n_reads, n_pos, 12, n_mol, n_frac=0.002, sorted_file=False)
+        compare(ctx.stage_reads(pos.astype(np.uint64), umi, score, 12, merge=1), orc.stage_reads(dense_ids(pos), umi, score, 12, 1))
+
+
 def test_local_order_with_64_bit_order_keys():
     """Positions of up to 1,024 entries are ordered by a wave each (no sort): with 32-bit order keys where the
     freq field and the read index fit them together, else with 64-bit ones -- forced here through the

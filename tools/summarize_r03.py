@@ -51,8 +51,7 @@ def counters(P, sub):
 
 
 doc = json.load(open(OUT)) if os.path.exists(OUT) else {"round": 3, "configs": {}}
-mine = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()
-        for f in glob.glob(os.path.join(ROOT, "umi_collapse_rs_amd", "csrc", "*"))}
+mine = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in bench.stamped_sources()}
 for P in sorted(glob.glob(os.path.join(BASE, "c*"))):
     cfg = os.path.basename(P)[1:]
     stats_csv = glob.glob(os.path.join(P, "trace", "*kernel_stats.csv"))
@@ -75,11 +74,13 @@ for P in sorted(glob.glob(os.path.join(BASE, "c*"))):
     for src, dst in (("bench_under_rocprof.log", "bench_under_rocprof"), ("bench_plain.log", "bench_line")):
         line = [l for l in open(os.path.join(P, src)) if l.startswith("{")][-1]
         lines[dst] = json.loads(line)
-        open(os.path.join(ROOT, "profiles", "r03_config%s_%s_%s.json" % (cfg, dst, tag)), "w").write(line)
+        if dst != "bench_line":  # (the plain lines kept in profiles/ are tools/final_r03.sh's: taken after this file exists)
+            open(os.path.join(ROOT, "profiles", "r03_config%s_%s_%s.json" % (cfg, dst, tag)), "w").write(line)
     sha_file = {}
     for l in open(os.path.join(P, "sources.sha256")):
         h, f = l.split()
-        sha_file[os.path.basename(f)] = h
+        if os.path.basename(f) in mine:  # (the staging's sources are not part of the stamp)
+            sha_file[os.path.basename(f)] = h
     if mine != sha_file:
         print("WARNING config %s: sources changed since the profile was taken:" % cfg,
               sorted(k for k in mine if mine[k] != sha_file.get(k)))

@@ -908,7 +908,10 @@ int stage_impl(void *workspace, const uint64_t *d_align, int align_bits, const u
     stage_rank_sums_kernel<<<n_blocks, 256, 0, s>>>(b.file_flags, n_groups, b.rank_rec, b.tile_sums);
     STAGE_TRY(scan_spine_u64(b.tile_sums, n_blocks, s));
     stage_position_rank_kernel<<<grid_for(B), 256, 0, s>>>(b.bfirst, B, b.rank_rec, b.tile_sums, b.brank_of);
-    if (pmax <= LOCAL_MAX) { // ---- 3'. every position fits a wave's LDS: ordered where it lies, no sort
+    // ---- 3'. every position fits a wave's LDS: ordered where it lies, no sort.  (A wave per position pays
+    // where positions hold some tens of entries; a file of singletons -- shallow sequencing -- is 10^7
+    // positions of one entry each, a trip to memory per wave and position: the sort below does not care.)
+    if (pmax <= LOCAL_MAX && (uint64_t)E >= 16ull * B) {
         uint64_t *size_by_rank = b.keyA, *end_by_rank = b.keyB; // (the read sort's buffers are free)
         stage_rank_sizes_kernel<<<grid_for(B), 256, 0, s>>>(b.pos_start, b.brank_of, B, size_by_rank);
         STAGE_TRY(scan_inclusive_u64(size_by_rank, end_by_rank, B, b.tmp, b.tmp_bytes, s));
