@@ -99,7 +99,7 @@ const char *umi_last_error(void);
  *   "profile"        0/1: record HIP events, fill the ms_* fields of umi_stats
  *   "edge_capacity"  initial capacity of the permitted-pair list, entries (it grows by itself)
  *   "fused_max"      0..128 (default 128): largest bucket the fused one-wave-per-bucket kernel takes
- *   "fused_blocks"   1..64 (default 12): 256-thread blocks per CU of that kernel's persistent grid
+ *   "fused_blocks"   1..64 (default 20): 256-thread blocks per CU of that kernel's persistent grid
  *   "fused_sliced"   0/1 (default 1): that kernel's bit-sliced body for k <= 3 (0: columns one by one)
  *   "small_max"      (default 1024) largest bucket taken as 64-row popcount chunks; above, 2048-row tiles
  *   "seg_index"      0/1 (default 1): buckets of at least "seg_min" entries (default 512) are cut into

@@ -188,7 +188,7 @@ struct umi_ctx {
     uint32_t bs_tab_waves = 0; // one-wave blocks of the item walk (0: 128 per CU; items are dealt
                                // statically over them, the dispatcher evens out the rest)
     uint32_t fused_max = FUSED_MAX;
-    uint32_t fused_blocks = 12; // 256-thread blocks per CU of the fused kernel's persistent grid
+    uint32_t fused_blocks = 20; // 256-thread blocks per CU of the fused kernel's persistent grid
     bool fused_sliced = true;
     int bs_unit = 2;
     bool bs_sorted = LEGACY_DEFAULT; // sort large buckets by key and reuse prefix state along column runs

@@ -966,11 +966,24 @@ __global__ __launch_bounds__(256) void small_bucket_kernel(const uint64_t *__res
                                                            int umi_len, int32_t adj_max_freq,
                                                            unsigned long long *__restrict__ counters)
 {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    // Positions are dealt statically to the BLOCKS (position b to block b mod the grid) and taken one by
+    // one by the block's four waves from a counter in LDS: a position of 65..128 entries costs 2.2x one
+    // of up to 64, and with positions dealt to the waves themselves the busiest SIMD of config 3 carried
+    // 13 % more than the mean (a counter in global memory instead: DESIGN.md section 5 -- 5-10x slower).
+    __shared__ uint32_t next_of_block;
+    if (threadIdx.x == 0) next_of_block = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     unsigned int bad = 0, n_kept = 0; // per lane; summed over the block at the end
-    for (uint32_t b = wave; b < n_buckets; b += n_waves) {
+    auto draw = [&]() -> uint32_t {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&next_of_block, 1u);
+        return blockIdx.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)i) * gridDim.x;
+    };
+    uint32_t b_next = draw();
+    while (b_next < n_buckets) {
+        const uint32_t b = b_next;
+        b_next = draw(); // (asked for before the work: the answer is there when it is wanted)
         const uint64_t s64 = bucket_off[b], e64 = bucket_off[b + 1];
         const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)s64);
         const uint32_t end = __builtin_amdgcn_readfirstlane((uint32_t)e64);
@@ -1272,10 +1285,12 @@ hipError_t launch_small_buckets(const uint64_t *keys, const uint64_t *nmask, con
                                 unsigned long long *counters, uint32_t max_blocks, hipStream_t s)
 {
     if (n_buckets == 0 || fused_max < 1) return hipSuccess;
-    // The waves walk the bucket table with the stride of the grid.  Measured on 10^5 positions of ~60
-    // UMIs (config 3): 4 blocks per CU 124 us, 6 114, 8 104, 12 and 16 98, 24 123, 32 106 -- somewhat
-    // more blocks than a CU holds at once even out the waves' unequal shares, many more leave the
-    // last ones to work alone.  max_blocks comes from the context ("fused_blocks" per CU, default 12).
+    // The blocks walk the bucket table with the stride of the grid, a block's waves take its positions
+    // one by one.  Measured on 10^5 positions of ~60 UMIs (config 3), blocks per CU: kernel us -- 8: 103,
+    // 12: 100, 16: 96.5, 20: 96.4, 24: 98, 32: 125, 48: 172 (a CU holds 8 at once: more, smaller shares
+    // even out what the positions' unequal costs leave, many more are launches of their own); with
+    // positions dealt to the waves themselves it was 8: 104, 12: 98, 16: 98, 24: 123.  max_blocks comes
+    // from the context ("fused_blocks" per CU, default 20).
     const uint32_t blocks = grid_for((uint64_t)n_buckets * 64, 256, max_blocks);
     const int kb = (sliced && k >= 0 && k <= 3) ? k : -1;
     if (mode == MODE_DIRECTIONAL) {
