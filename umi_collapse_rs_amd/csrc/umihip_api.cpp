@@ -233,6 +233,8 @@ struct umi_ctx {
     unsigned long long *h_counters = nullptr; // pinned mirror of the control block (CTRL_BYTES), then, in a line of
                                               // its own, the sequence number of the last copy that has arrived
     unsigned long long ctrl_seq = 0;          // ... and of the last copy asked for
+    int dag_rounds_ahead = DAG_ROUNDS;        // one-way rounds enqueued before the host first looks: as many as the
+                                              // call before needed (a quiet round returns at once)
     // umi_dedup_batch_device_begin / umi_dedup_batch_end: a call whose work is all on the stream and whose
     // control block has not been looked at yet (deferred), or whose result waits to be handed out
     struct PendingCall {
@@ -1145,6 +1147,11 @@ class Pipeline {
         uint32_t *d_changed = ctx->d_changed();
         const bool have_pairs = need_pairs && n_tasks;
         uint64_t cap = std::max<uint64_t>(ctx->edge_capacity, 1024);
+        // rounds along the one-way pairs enqueued ahead of the host's look (the last as the check beside the
+        // finalize pass): what the call before on this context needed -- a position of clusters (chains of
+        // one-way pairs down a freq ladder) takes five or six where a uniform one takes three, and each look
+        // of the host in between costs a wait and a second finalize pass
+        const int ahead = std::min(std::max(ctx->dag_rounds_ahead, DAG_ROUNDS), MAX_ROUNDS_PER_SYNC);
         for (int attempt = 0;; attempt++) {
             if (have_pairs) {
                 uint64_t ovf_cap = 0;
@@ -1161,8 +1168,8 @@ class Pipeline {
                 HIP_TRY(launch_collapse_flatten(cd, s));
                 // (the last of them as a check beside the finalize pass: in the common case it would change
                 // nothing, and the kept mask stands)
-                for (int r = 0; r < DAG_ROUNDS - 1; r++) HIP_TRY(launch_collapse_round(cd, r, s));
-                HIP_TRY(launch_collapse_finalize(cd, s, DAG_ROUNDS - 1));
+                for (int r = 0; r < ahead - 1; r++) HIP_TRY(launch_collapse_round(cd, r, s));
+                HIP_TRY(launch_collapse_finalize(cd, s, ahead - 1));
             } else { // no pair of this call reaches the edge list: every entry outside the fused buckets survives
                 HIP_TRY(launch_finalize(d_label, d_ranges, (uint32_t)pl.ranges.size(), n, d_kept, d_root, d_cnt, s));
             }
@@ -1193,8 +1200,9 @@ class Pipeline {
         }
         st.n_edges = n_edges + n_direct;
         int rounds = have_pairs && st.n_edges ? 1 : 0;
-        for (int r = 0; have_pairs && r < DAG_ROUNDS; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
-        if (have_pairs && ctx->h_changed()[DAG_ROUNDS - 1]) { // a deeper chain of one-way pairs than that
+        for (int r = 0; have_pairs && r < ahead; r++) rounds += (r == 0 || ctx->h_changed()[r - 1]) ? 1 : 0;
+        const int rounds_first = rounds;
+        if (have_pairs && ctx->h_changed()[ahead - 1]) { // a deeper chain of one-way pairs than that
             // (comp[] is flat and lab[] only ever falls: the rounds go on where the first ones stopped)
             const CollapseDesc cd = collapse_desc();
             if ((rc = run_rounds(ctx, s, [&](uint32_t *, int r) { return launch_collapse_round(cd, r, s); }, rounds, 4)))
@@ -1203,6 +1211,8 @@ class Pipeline {
             HIP_TRY(launch_collapse_finalize(cd, s));
             if ((rc = read_control())) return rc;
         }
+        // (rounds = 1 for the union-find pass + the rounds that ran, the last of them quiet)
+        if (have_pairs) ctx->dag_rounds_ahead = std::max(DAG_ROUNDS, (rounds > rounds_first ? rounds : rounds_first) - 1);
         st.n_rounds = (uint32_t)rounds;
         return finish_stats();
     }
